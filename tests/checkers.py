@@ -1,0 +1,390 @@
+"""ctypes bindings of the two TEST-ONLY checkers:
+
+  * ``Oracle``  -- oracle/liboracle.so, our C restatement of the reference path
+  * ``Ref``     -- oracle/_ref/libadmm_ref.so, the REAL reference compiled from
+                   /root/reference (only exists where oracle/Makefile built it)
+
+Nothing in the product package imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1]
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(ip)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libadmm_ref.so"))
+
+
+class _Sys:
+    """Common python face of oracle / reference systems."""
+
+    prefix = None
+    lib = None
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def settings(self, dt, iters):
+        raise NotImplementedError
+
+    def add_nodes(self, x, m):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        m = np.ascontiguousarray(m, dtype=np.float64).ravel()
+        return self._f("add_nodes")(self.h, x.size, _d(x), _d(m))
+
+    def add_forces(self, kind, idx, params):
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, KIND_NODES[kind])
+        n = idx.shape[0]
+        params = np.ascontiguousarray(np.broadcast_to(np.asarray(params, dtype=np.float64), (n, KIND_PARAMS[kind])))
+        r = self._f("add_forces")(self.h, kind, n, _i(idx), _d(params))
+        assert r >= 0
+        return r
+
+    def add_moving_anchor(self, idx, pos, active=True, weight=-1.0):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        return self._f("add_moving_anchor")(self.h, int(idx), _d(pos), int(active), float(weight))
+
+    def set_control_point(self, handle, pos, active=True):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        self._f("set_control_point")(self.h, handle, _d(pos), int(active))
+
+    def add_gravity(self, g):
+        self._f("add_gravity")(self.h, float(g[0]), float(g[1]), float(g[2]))
+
+    def initialize(self):
+        return bool(self._f("initialize")(self.h))
+
+    def step(self):
+        return bool(self._f("step")(self.h))
+
+    @property
+    def dof(self):
+        return self._f("dof")(self.h)
+
+    @property
+    def rows(self):
+        return self._f("rows")(self.h)
+
+    @property
+    def n_forces(self):
+        return self._f("n_forces")(self.h)
+
+    def D_triplets(self):
+        n = self._f("D_nnz")(self.h)
+        r = np.zeros(n, np.int32); c = np.zeros(n, np.int32); v = np.zeros(n)
+        self._f("get_D")(self.h, _i(r), _i(c), _d(v))
+        return r, c, v
+
+    def L_nnz(self):
+        return self._f("L_nnz")(self.h)
+
+    def time_steps(self, frames):
+        return self._f("time_steps")(self.h, frames)
+
+
+class Ref(_Sys):
+    prefix = "ref_"
+
+    @classmethod
+    def load(cls):
+        if cls.lib is None:
+            lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libadmm_ref.so"))
+            lib.ref_create.restype = C.c_void_p
+            for n in ("destroy", "settings", "set_control_point", "add_gravity", "get_x", "set_x", "get_v", "set_v", "get_u",
+                      "get_z", "get_wdiag", "get_D", "svd3", "svd32", "recompute_weights", "set_force_weight", "get_masses",
+                      "get_control_point", "add_wind"):
+                getattr(lib, "ref_" + n).restype = None
+            lib.ref_D_nnz.restype = C.c_long
+            lib.ref_L_nnz.restype = C.c_long
+            lib.ref_force_weight.restype = C.c_double
+            lib.ref_time_steps.restype = C.c_double
+            lib.ref_elapsed.restype = C.c_double
+            lib.ref_settings.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+            lib.ref_add_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+            lib.ref_add_moving_anchor.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, C.c_double]
+            lib.ref_set_force_weight.argtypes = [C.c_void_p, C.c_int, C.c_double]
+            lib.ref_add_wind.argtypes = [C.c_void_p, C.c_int, ip, C.c_double, C.c_double, C.c_double]
+            lib.ref_project_single.argtypes = [C.c_int, dp, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp, ip, dp]
+            for n in ("add_nodes", "add_forces", "set_control_point", "initialize", "step", "dof", "rows", "n_forces",
+                      "get_x", "set_x", "get_v", "set_v", "get_u", "get_z", "get_wdiag", "force_global_idx", "force_weight",
+                      "D_nnz", "get_D", "L_nnz", "get_hyper_state", "set_hyper_state", "time_steps", "destroy",
+                      "recompute_weights", "get_masses", "get_control_point", "elapsed"):
+                fn = getattr(lib, "ref_" + n)
+                if fn.argtypes is None:
+                    fn.argtypes = None  # first arg is the handle; set below where needed
+            cls.lib = lib
+        return cls.lib
+
+    def __init__(self):
+        self.load()
+        self.h = C.c_void_p(self.lib.ref_create())
+
+    def __del__(self):
+        try:
+            self.lib.ref_destroy(self.h)
+        except Exception:
+            pass
+
+    def settings(self, dt, iters):
+        self.lib.ref_settings(self.h, dt, iters, 0)
+
+    def _vec(self, name, n):
+        a = np.zeros(n)
+        getattr(self.lib, "ref_get_" + name)(self.h, _d(a))
+        return a
+
+    @property
+    def x(self):
+        return self._vec("x", self.dof)
+
+    @x.setter
+    def x(self, val):
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        self.lib.ref_set_x(self.h, _d(val))
+
+    @property
+    def v(self):
+        return self._vec("v", self.dof)
+
+    @property
+    def masses(self):
+        return self._vec("masses", self.dof)
+
+    @property
+    def u(self):
+        return self._vec("u", self.rows)
+
+    @property
+    def z(self):
+        return self._vec("z", self.rows)
+
+    @property
+    def wdiag(self):
+        return self._vec("wdiag", self.rows)
+
+    def global_idx(self):
+        return np.array([self.lib.ref_force_global_idx(self.h, i) for i in range(self.n_forces)], np.int64)
+
+    def weights(self):
+        return np.array([self.lib.ref_force_weight(self.h, i) for i in range(self.n_forces)])
+
+    def hyper_state(self, i):
+        st = np.zeros(4)
+        it = self.lib.ref_get_hyper_state(self.h, i, _d(st))
+        return st, it
+
+    def add_wind(self, tris, direction):
+        tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        self.lib.ref_add_wind(self.h, tris.shape[0], _i(tris), *[float(d) for d in direction])
+
+    def recompute_weights(self):
+        self.lib.ref_recompute_weights(self.h)
+
+    def set_force_weight(self, i, w):
+        self.lib.ref_set_force_weight(self.h, i, w)
+
+    @classmethod
+    def project_single(cls, kind, x_rest, params, Dx, u0=None, state=None, dt=0.04):
+        """n_calls consecutive project() calls of one stand-alone element."""
+        lib = cls.load()
+        rows = KIND_ROWS[kind]
+        Dx = np.ascontiguousarray(Dx, dtype=np.float64).reshape(-1, rows)
+        n = Dx.shape[0]
+        u = np.zeros(rows) if u0 is None else np.array(u0, dtype=np.float64)
+        z_out = np.zeros((n, rows)); u_out = np.zeros((n, rows))
+        st = np.array([1, 1, 1, 1], dtype=np.float64) if state is None else np.array(state, dtype=np.float64)
+        iters = np.zeros(n, np.int32)
+        init = np.zeros(16)
+        x_rest = np.ascontiguousarray(x_rest, dtype=np.float64)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        r = lib.ref_project_single(kind, _d(x_rest), _d(params), dt, n, _d(Dx), _d(u), _d(z_out), _d(u_out), _d(st), _i(iters), _d(init))
+        assert r == 0
+        return dict(z=z_out, u=u_out, state=st, n_iters=iters, init=init)
+
+    @classmethod
+    def svd3(cls, F):
+        lib = cls.load()
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+        lib.ref_svd3(_d(F), _d(U), _d(S), _d(V))
+        return U, S, V
+
+    @classmethod
+    def svd32(cls, F):
+        lib = cls.load()
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        U = np.zeros(9); S = np.zeros(2); V = np.zeros(4)
+        lib.ref_svd32(_d(F), _d(U), _d(S), _d(V))
+        return U, S, V
+
+
+class OrcForce(C.Structure):
+    _fields_ = [("kind", C.c_int), ("idx", C.c_int * 4), ("params", C.c_double * 4), ("weight", C.c_double),
+                ("B", C.c_double * 12), ("measure", C.c_double), ("alpha", C.c_double * 4), ("pos", C.c_double * 3),
+                ("active", C.c_int), ("moving", C.c_int), ("state", C.c_double * 4), ("n_iters", C.c_int),
+                ("n_fev", C.c_int), ("global_idx", C.c_int)]
+
+
+class Oracle(_Sys):
+    prefix = "orc_"
+
+    @classmethod
+    def load(cls):
+        if cls.lib is None:
+            path = os.path.join(ORACLE_DIR, "liboracle.so")
+            if not os.path.exists(path):
+                build_oracle()
+            lib = C.CDLL(path)
+            lib.orc_create.restype = C.c_void_p
+            for n in ("x", "v", "u", "z", "wdiag"):
+                getattr(lib, "orc_" + n).restype = dp
+                getattr(lib, "orc_" + n).argtypes = [C.c_void_p]
+            lib.orc_get_force.restype = C.POINTER(OrcForce)
+            lib.orc_get_force.argtypes = [C.c_void_p, C.c_int]
+            lib.orc_D_nnz.restype = C.c_long
+            lib.orc_L_nnz.restype = C.c_long
+            lib.orc_time_steps.restype = C.c_double
+            lib.orc_settings.argtypes = [C.c_void_p, C.c_double, C.c_int]
+            lib.orc_set_layout.argtypes = [C.c_void_p, C.c_int]
+            lib.orc_add_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+            lib.orc_add_moving_anchor.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, C.c_double]
+            lib.orc_force_construct.argtypes = [C.POINTER(OrcForce), C.c_int, ip, dp]
+            lib.orc_force_initialize.argtypes = [C.POINTER(OrcForce), dp]
+            lib.orc_force_project.argtypes = [C.POINTER(OrcForce), C.c_double, dp, dp, dp]
+            for n in ("settings", "set_layout", "add_gravity", "destroy", "get_D", "set_control_point", "svd3", "svd32",
+                      "oriented_svd", "force_construct", "force_initialize", "force_project"):
+                getattr(lib, "orc_" + n).restype = None
+            cls.lib = lib
+        return cls.lib
+
+    def __init__(self, ref_layout=False):
+        self.load()
+        self.h = C.c_void_p(self.lib.orc_create())
+        self.lib.orc_set_layout(self.h, int(ref_layout))
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def settings(self, dt, iters):
+        self.lib.orc_settings(self.h, dt, iters)
+
+    def _view(self, name, n):
+        p = getattr(self.lib, "orc_" + name)(self.h)
+        return np.ctypeslib.as_array(p, shape=(n,)) if n else np.zeros(0)
+
+    @property
+    def x(self):
+        return self._view("x", self.dof).copy()
+
+    @x.setter
+    def x(self, val):
+        self._view("x", self.dof)[:] = val
+
+    @property
+    def v(self):
+        return self._view("v", self.dof).copy()
+
+    @property
+    def u(self):
+        return self._view("u", self.rows).copy()
+
+    @property
+    def z(self):
+        return self._view("z", self.rows).copy()
+
+    @property
+    def wdiag(self):
+        return self._view("wdiag", self.rows).copy()
+
+    def force(self, i):
+        return self.lib.orc_get_force(self.h, i).contents
+
+    def global_idx(self):
+        return np.array([self.force(i).global_idx for i in range(self.n_forces)], np.int64)
+
+    def weights(self):
+        return np.array([self.force(i).weight for i in range(self.n_forces)])
+
+    def hyper_state(self, i):
+        f = self.force(i)
+        return np.array(list(f.state)), f.n_iters
+
+    @classmethod
+    def project_single(cls, kind, x_rest, params, Dx, u0=None, state=None, dt=0.04):
+        lib = cls.load()
+        rows = KIND_ROWS[kind]
+        Dx = np.ascontiguousarray(Dx, dtype=np.float64).reshape(-1, rows)
+        n = Dx.shape[0]
+        f = OrcForce()
+        idx = np.arange(4, dtype=np.int32)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        x_rest = np.ascontiguousarray(x_rest, dtype=np.float64)
+        lib.orc_force_construct(C.byref(f), kind, _i(idx), _d(params))
+        lib.orc_force_initialize(C.byref(f), _d(x_rest))
+        if state is not None:
+            for j in range(4):
+                f.state[j] = state[j]
+        u = np.zeros(rows) if u0 is None else np.array(u0, dtype=np.float64)
+        z = np.zeros(rows)
+        z_out = np.zeros((n, rows)); u_out = np.zeros((n, rows)); iters = np.zeros(n, np.int32); fev = np.zeros(n, np.int32)
+        for c in range(n):
+            d = np.ascontiguousarray(Dx[c])
+            lib.orc_force_project(C.byref(f), dt, _d(d), _d(u), _d(z))
+            z_out[c] = z; u_out[c] = u; iters[c] = f.n_iters; fev[c] = f.n_fev
+        init = np.zeros(16)
+        init[0] = f.weight
+        if kind in (2, 3, 4, 5):
+            init[1:13] = list(f.B); init[13] = f.measure
+        elif kind == 6:
+            init[1:7] = list(f.B)[:6]; init[7] = f.measure
+        elif kind == 7:
+            init[1:5] = list(f.alpha)
+        elif kind == 1:
+            init[1] = f.measure
+        return dict(z=z_out, u=u_out, state=np.array(list(f.state)), n_iters=iters, n_fev=fev, init=init)
+
+    @classmethod
+    def svd3(cls, F):
+        lib = cls.load()
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+        lib.orc_svd3(_d(F), _d(U), _d(S), _d(V))
+        return U, S, V
+
+    @classmethod
+    def svd32(cls, F):
+        lib = cls.load()
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        U = np.zeros(9); S = np.zeros(2); V = np.zeros(4)
+        lib.orc_svd32(_d(F), _d(U), _d(S), _d(V))
+        return U, S, V
