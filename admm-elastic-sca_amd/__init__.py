@@ -1,0 +1,317 @@
+"""admm-elastic-sca_amd: MI355X-native ADMM elastic solver (hot path of
+mattoverby/admm-elastic-sca) -- Python plumbing over the C ABI.
+
+The product is libadmm_hip.so (HIP kernels + C ABI, include/admm_hip.h).  This
+module only binds it with ctypes for bench.py / tests and mirrors the
+reference's ``admm::System`` surface (``add_nodes``, ``forces``, ``initialize``,
+``step``, ``m_x``/``m_v``; reference deps/admm-elastic-sca/src/system/System.hpp:29-76)
+so that scene code reads like the reference's samples.  There is no CPU
+fallback: without the library or without a GPU every compute call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import meshgen  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libadmm_hip.so")
+
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1]
+KIND_STATE = [0, 0, 0, 0, 4, 4, 0, 0]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_nodes", "n_elems_total", "n_elems_local", "rows_compact", "nnz_A", "nnz_L",
+                                         "panel_bytes", "n_supernodes", "n_levels", "max_super_cols", "max_super_rows",
+                                         "solve_contrib_rows")] + \
+               [(n, C.c_double) for n in ("t_order_s", "t_symbolic_s", "t_numeric_s", "t_upload_s")] + \
+               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Timing(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("prologue_ms", "local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms",
+                                         "epilogue_ms", "total_ms")] + [("iters", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class AdmmHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    return _build.build(force=force, verbose=verbose)
+
+
+def lib():
+    """Loads libadmm_hip.so (building it if absent).  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.admm_hip_last_error.restype = C.c_char_p
+        L.admm_hip_last_error.argtypes = [C.c_void_p]
+        L.admm_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.admm_hip_destroy.argtypes = [C.c_void_p]
+        L.admm_hip_destroy.restype = None
+        L.admm_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.admm_hip_set_timestep.argtypes = [C.c_void_p, C.c_double]
+        L.admm_hip_add_nodes.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int)]
+        L.admm_hip_add_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, C.POINTER(C.c_int)]
+        L.admm_hip_add_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.admm_hip_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.admm_hip_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.admm_hip_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.admm_hip_finalize.argtypes = [C.c_void_p]
+        L.admm_hip_set_weights.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.admm_hip_recompute_weights.argtypes = [C.c_void_p]
+        L.admm_hip_update_anchors.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
+        L.admm_hip_step.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_sync.argtypes = [C.c_void_p]
+        for n in ("get_x", "get_v"):
+            getattr(L, "admm_hip_" + n).argtypes = [C.c_void_p, _dp]
+        for n in ("set_x", "set_v", "local_step_only"):
+            getattr(L, "admm_hip_" + n).argtypes = [C.c_void_p, _dp]
+        L.admm_hip_read_local.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _ip]
+        L.admm_hip_write_local.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.admm_hip_read_rest.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
+        L.admm_hip_solve_only.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_apply_A.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_debug_panel_solve_host.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.admm_hip_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+class System:
+    """Python face of the C ABI with the reference's System vocabulary.
+
+    device_id < 0 gives a host-only context (assembly + factorization only;
+    every device call raises) -- used by the CPU test-suite."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.admm_hip_create(C.byref(h), int(device_id))
+        if rc != 0:
+            raise AdmmHipError("admm_hip_create(device %d) failed with code %d: no usable MI355X/HIP device "
+                               "(this package has no CPU fallback)" % (device_id, rc))
+        self.h = h
+        self.batches = []  # (kind, n)
+        self.n_nodes = 0
+        self._cb = None
+        if stream is not None:
+            self._chk(self.L.admm_hip_set_stream(self.h, C.c_void_p(stream)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.admm_hip_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AdmmHipError("admm_hip error %d: %s" % (rc, self.L.admm_hip_last_error(self.h).decode()))
+
+    # ---- setup (System.hpp:36-63) ----
+    def set_timestep(self, dt):
+        self._chk(self.L.admm_hip_set_timestep(self.h, float(dt)))
+
+    def add_nodes(self, x, m):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        m = np.ascontiguousarray(m, dtype=np.float64).ravel()
+        assert x.size == m.size and x.size % 3 == 0
+        tot = C.c_int()
+        self._chk(self.L.admm_hip_add_nodes(self.h, x.size // 3, _d(x), _d(m), C.byref(tot)))
+        self.n_nodes = tot.value
+        return tot.value
+
+    def add_forces(self, kind, idx, params, targets=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, KIND_NODES[kind])
+        n = idx.shape[0]
+        params = np.ascontiguousarray(np.broadcast_to(np.asarray(params, dtype=np.float64), (n, KIND_PARAMS[kind])))
+        tg = None if targets is None else np.ascontiguousarray(targets, dtype=np.float64).reshape(n, 3)
+        b = C.c_int()
+        self._chk(self.L.admm_hip_add_batch(self.h, kind, n, _i(idx), _d(params), _d(tg), C.byref(b)))
+        self.batches.append((kind, n))
+        return b.value
+
+    def add_gravity(self, g):
+        self._chk(self.L.admm_hip_add_gravity(self.h, float(g[0]), float(g[1]), float(g[2])))
+
+    def set_gravity(self, which, g):
+        self._chk(self.L.admm_hip_set_gravity(self.h, which, float(g[0]), float(g[1]), float(g[2])))
+
+    def set_shard(self, rank, world):
+        self._chk(self.L.admm_hip_set_shard(self.h, rank, world))
+
+    def set_allreduce(self, pyfunc):
+        """pyfunc(dev_ptr:int, count:int, stream:int) -> 0 on success."""
+        def tramp(user, buf, count, stream):
+            try:
+                return int(pyfunc(buf or 0, int(count), stream or 0) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                print("allreduce hook raised:", e)
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        self._chk(self.L.admm_hip_set_allreduce(self.h, self._cb, None))
+
+    def initialize(self):
+        self._chk(self.L.admm_hip_finalize(self.h))
+        return True
+
+    def recompute_weights(self):
+        self._chk(self.L.admm_hip_recompute_weights(self.h))
+
+    def set_weights(self, batch, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self._chk(self.L.admm_hip_set_weights(self.h, batch, _d(w)))
+
+    def update_anchors(self, batch, targets=None, active=None):
+        tg = None if targets is None else np.ascontiguousarray(targets, dtype=np.float64)
+        ac = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+        self._chk(self.L.admm_hip_update_anchors(self.h, batch, _d(tg), _i(ac)))
+
+    # ---- stepping (System.hpp:65) ----
+    def step(self, admm_iters):
+        self._chk(self.L.admm_hip_step(self.h, int(admm_iters)))
+
+    def sync(self):
+        self._chk(self.L.admm_hip_sync(self.h))
+
+    # ---- state ----
+    def _getn(self, fn):
+        a = np.zeros(3 * self.n_nodes)
+        self._chk(fn(self.h, _d(a)))
+        return a
+
+    @property
+    def m_x(self):
+        return self._getn(self.L.admm_hip_get_x)
+
+    @m_x.setter
+    def m_x(self, val):
+        val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+        assert val.size == 3 * self.n_nodes
+        self._chk(self.L.admm_hip_set_x(self.h, _d(val)))
+
+    @property
+    def m_v(self):
+        return self._getn(self.L.admm_hip_get_v)
+
+    @m_v.setter
+    def m_v(self, val):
+        val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+        self._chk(self.L.admm_hip_set_v(self.h, _d(val)))
+
+    # ---- parity / introspection ----
+    def info(self):
+        inf = Info()
+        self._chk(self.L.admm_hip_get_info(self.h, C.byref(inf)))
+        return inf.as_dict()
+
+    def local_range(self, batch):
+        kind, n = self.batches[batch]
+        inf = self.info()
+        r, w = inf["rank"], inf["world"]
+        return n * r // w, n * (r + 1) // w
+
+    def read_local(self, batch):
+        kind, _ = self.batches[batch]
+        a, b = self.local_range(batch)
+        n = b - a
+        rows = KIND_ROWS[kind]
+        u = np.zeros((n, rows)); z = np.zeros((n, rows))
+        st = np.zeros((n, 4 if KIND_STATE[kind] else 3)); it = np.zeros(n, np.int32)
+        self._chk(self.L.admm_hip_read_local(self.h, batch, _d(u), _d(z), _d(st), _i(it)))
+        return dict(u=u, z=z, state=st, n_iters=it)
+
+    def write_local(self, batch, u=None, state=None):
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        state = None if state is None else np.ascontiguousarray(state, dtype=np.float64)
+        self._chk(self.L.admm_hip_write_local(self.h, batch, _d(u), _d(state)))
+
+    def read_rest(self, batch):
+        kind, n = self.batches[batch]
+        w = np.zeros(n); rest = np.zeros((n, 12)); g = np.zeros(n, np.int32)
+        self._chk(self.L.admm_hip_read_rest(self.h, batch, _d(w), _d(rest), _i(g)))
+        return dict(weight=w, rest=rest, global_idx=g)
+
+    def local_step_only(self, x_cur):
+        x_cur = np.ascontiguousarray(x_cur, dtype=np.float64).ravel()
+        self._chk(self.L.admm_hip_local_step_only(self.h, _d(x_cur)))
+
+    def solve_only(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+        x = np.zeros_like(b)
+        self._chk(self.L.admm_hip_solve_only(self.h, _d(b), _d(x)))
+        return x
+
+    def apply_A(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        y = np.zeros_like(x)
+        self._chk(self.L.admm_hip_apply_A(self.h, _d(x), _d(y)))
+        return y
+
+    def debug_panel_solve_host(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+        x = np.zeros_like(b)
+        self._chk(self.L.admm_hip_debug_panel_solve_host(self.h, _d(b), _d(x)))
+        return x
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.admm_hip_enable_timing(self.h, int(on)))
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.L.admm_hip_get_timing(self.h, C.byref(t)))
+        return t.as_dict()
+
+
+def make_bar_system(nx, ny, nz, kind=KIND["TET_NH"], mu=1e5, lam=1e5, max_iter=5, density=1000.0, h=0.05, dt=0.04,
+                    gravity=(0.0, -9.8, 0.0), device_id=0, rank=0, world=1, stream=None):
+    """The synthetic bar of BASELINE.md section 4 config 4: tets first, then
+    StaticAnchors on the k = 0 face, gravity, lumped density-weighted mass."""
+    x, tets = meshgen.bar(nx, ny, nz, h)
+    m = meshgen.lumped_tet_mass(x, tets, density)
+    s = System(device_id=device_id, stream=stream)
+    s.set_timestep(dt)
+    s.add_nodes(x.ravel(), np.repeat(m, 3))
+    s.add_forces(kind, tets, [mu, lam, max_iter])
+    s.add_forces(KIND["ANCHOR"], meshgen.bar_anchor_nodes(nx, ny), [-1.0, 1.0])
+    s.add_gravity(gravity)
+    if world > 1:
+        s.set_shard(rank, world)
+    s.n_tets = tets.shape[0]
+    return s

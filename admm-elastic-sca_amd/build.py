@@ -1,0 +1,62 @@
+"""Builds libadmm_hip.so in-tree (admm-elastic-sca_amd/libadmm_hip.so).
+
+  dense.cpp, factor.cpp : host-side factorization, g++ -O3 -fopenmp
+  admm_hip.hip          : kernels + C ABI, hipcc --offload-arch=gfx950,
+                          -ffp-contract=off (operation order = reference's)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only
+container as well as on the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libadmm_hip.so")
+OBJ = os.path.join(HERE, "_build")
+
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wno-unknown-pragmas"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+             "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers += [os.path.join(HERE, "..", "include", f) for f in ("admm_hip.h", "admm_kinds.h")]
+    jobs = [
+        (["g++"] + HOST_FLAGS + ["-mavx2", "-mfma"], "dense.cpp", "dense.o"),
+        (["g++"] + HOST_FLAGS, "factor.cpp", "factor.o"),
+        ([hipcc] + HIP_FLAGS, "admm_hip.hip", "admm_hip.o"),
+    ]
+    objs = []
+    rebuilt = False
+    for cmd, src, obj in jobs:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, obj)
+        objs.append(o)
+        if force or _newer([s] + headers, o):
+            full = cmd + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(full))
+            subprocess.check_call(full)
+            rebuilt = True
+    if rebuilt or not os.path.exists(OUT):
+        full = [hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-lgomp"]
+        if verbose:
+            print(" ".join(full))
+        subprocess.check_call(full)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,795 @@
+// admm_hip.hip -- context, host orchestration and C ABI of libadmm_hip.so.
+// See include/admm_hip.h for the contract and DESIGN.md for the design.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/admm_hip.h"
+#include "factor.hpp"
+#include "force_init.hpp"
+#include "kernels_global.hpp"
+#include "kernels_local.hpp"
+
+extern "C" int omp_get_max_threads(void);
+
+using namespace admm_host;
+using admm_dev::BatchDev;
+using admm_dev::FactorDev;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Batch {
+    int kind = 0, n_total = 0, first = 0, n_local = 0;
+    std::vector<int32_t> idx;      // [n_total][nodes] original ids
+    std::vector<double> params;    // [n_total][P]
+    std::vector<double> targets;   // anchors [n_total][3]
+    bool moving = false;
+    std::vector<int32_t> active;   // anchors [n_total]
+    // finalize
+    std::vector<double> weight, rest, measure;  // [n_total], [n_total][12], [n_total]
+    std::vector<int32_t> global_idx;             // compact first row
+    std::vector<int32_t> corner_perm;            // [n_total][nodes]: stored corner c holds original corner corner_perm[c]
+    int64_t slot_base = 0;                       // first local force slot
+    int max_iter = 0;                            // largest L-BFGS max_iterations (hyperelastic kinds)
+    // device
+    int *d_idx = nullptr, *d_active = nullptr, *d_niters = nullptr;
+    double *d_rest = nullptr, *d_par = nullptr, *d_w2h2 = nullptr, *d_kblend = nullptr, *d_w2 = nullptr;
+    double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
+};
+
+struct LevelDev {
+    int n_cols = 0; int *d_cols = nullptr;                       // gather
+    int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
+    int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
+    int n_bwd = 0; int *d_bwd_sn = nullptr, *d_bwd_chunk = nullptr;
+};
+
+} // namespace
+
+struct admm_hip_ctx {
+    int device_id = -1;
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+    double dt = 0.04;
+    int rank = 0, world = 1;
+    admm_hip_allreduce_fn allreduce = nullptr; void *allreduce_user = nullptr;
+    bool finalized = false;
+    int leaf_size = 16;
+    // host state
+    int n_nodes = 0;
+    std::vector<double> x, v, m3;
+    std::vector<Batch> batches;
+    admm_dev::Gravity grav{};
+    SymCSC A;
+    Factor F;
+    admm_hip_info info{};
+    // device state (node arrays in factor order)
+    double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
+    double *d_fslot = nullptr; int64_t n_fslots = 0;
+    int64_t *d_inc_ptr = nullptr; int *d_inc_slot = nullptr;
+    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_gat_slot = nullptr;
+    int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_gat_ptr = nullptr;
+    std::vector<LevelDev> levels;
+    std::vector<void *> allocs;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[8] = {};
+    admm_hip_timing last_timing{};
+};
+
+namespace {
+
+int fail(admm_hip_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    fprintf(stderr, "admm_hip: %s\n", buf);
+    return code;
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, ADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+template <class T> int dalloc(admm_hip_ctx *ctx, T **p, size_t n) {
+    *p = nullptr;
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    ctx->allocs.push_back(q);
+    *p = (T *)q;
+    return ADMM_OK;
+}
+template <class T> int upload(admm_hip_ctx *ctx, T **p, const std::vector<T> &h) {
+    int rc = dalloc(ctx, p, h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ADMM_OK;
+}
+#define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+void free_device(admm_hip_ctx *ctx) {
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    ctx->allocs.clear();
+    ctx->levels.clear();
+}
+
+// scalar "G" matrix of an element: nodes x cols, so that K_e = dt^2 w^2 G G^T
+void element_G(int kind, const double *rest, double G[4][3], int &cols) {
+    std::memset(G, 0, sizeof(double) * 12);
+    switch (kind) {
+    case ADMM_KIND_ANCHOR: cols = 1; G[0][0] = 1.0; break;
+    case ADMM_KIND_SPRING: cols = 1; G[0][0] = 1.0; G[1][0] = -1.0; break;
+    case ADMM_KIND_TET_LINEAR: case ADMM_KIND_TET_VOLUME: case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK:
+        cols = 3; for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) G[c][r] = rest[c + 4 * r]; break;
+    case ADMM_KIND_TRI_STRAIN: cols = 2; for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) G[c][r] = rest[c + 3 * r]; break;
+    case ADMM_KIND_BEND: cols = 3; G[0][0] = 1.0; G[2][0] = -1.0; G[3][1] = 1.0; G[2][1] = -1.0; G[1][2] = 1.0; G[2][2] = -1.0; break;
+    default: cols = 0;
+    }
+}
+
+int idx_stride(int kind) {
+    switch (kind) { case ADMM_KIND_ANCHOR: return 1; case ADMM_KIND_SPRING: return 2; default: return 4; }
+}
+
+// ---- host part of finalize: rest data, rows, A_s, ordering, factorization ----
+int host_assemble(admm_hip_ctx *ctx, bool reuse_rest) {
+    const int n = ctx->n_nodes;
+    const double dt = ctx->dt;
+    int64_t row = 0, ntot = 0;
+    std::vector<int> ti, tj; std::vector<double> tv;
+    for (int i = 0; i < n; ++i) {
+        const double m = ctx->m3[3 * (size_t)i];
+        if (ctx->m3[3 * (size_t)i + 1] != m || ctx->m3[3 * (size_t)i + 2] != m)
+            return fail(ctx, ADMM_ERR_UNSUPPORTED, "node %d has different masses for x/y/z; the accelerated path factors the scalar system A_s (x) I3", i);
+        ti.push_back(i); tj.push_back(i); tv.push_back(m);
+    }
+    for (Batch &b : ctx->batches) {
+        const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind];
+        if (!reuse_rest) {
+            b.weight.assign(b.n_total, 0.0); b.rest.assign((size_t)b.n_total * 12, 0.0); b.measure.assign(b.n_total, 0.0);
+            b.global_idx.assign(b.n_total, 0);
+        }
+        for (int e = 0; e < b.n_total; ++e) {
+            const int *id = b.idx.data() + (size_t)e * nn;
+            for (int c = 0; c < nn; ++c) if (id[c] < 0 || id[c] >= n) return fail(ctx, ADMM_ERR_ARG, "batch element %d references node %d (have %d nodes)", e, id[c], n);
+            if (!reuse_rest) {
+                if (!force_initialize(b.kind, id, b.params.data() + (size_t)e * np, ctx->x.data(), &b.weight[e], &b.rest[(size_t)e * 12]))
+                    return fail(ctx, ADMM_ERR_UNSUPPORTED, "force kind %d is not accelerated", b.kind);
+                b.measure[e] = force_measure(b.kind, id, ctx->x.data());
+                if (b.kind == ADMM_KIND_ANCHOR && !b.moving) for (int j = 0; j < 3; ++j) b.targets[3 * (size_t)e + j] = ctx->x[3 * (size_t)id[0] + j];
+            }
+            b.global_idx[e] = (int32_t)row; row += rows;
+            double G[4][3]; int cols;
+            element_G(b.kind, &b.rest[(size_t)e * 12], G, cols);
+            const double w = b.weight[e];
+            for (int a = 0; a < nn; ++a) for (int c = 0; c < nn; ++c) {
+                if (id[a] < id[c]) continue; // lower triangle (i >= j); equal ids handled once per ordered pair below
+                if (id[a] == id[c] && a < c) continue;
+                double sacc = 0.0;
+                for (int q = 0; q < cols; ++q) sacc += (((dt * dt) * G[a][q]) * w) * w * G[c][q];
+                if (id[a] == id[c] && a != c) sacc *= 2.0; // both (a,c) and (c,a) land on the same diagonal entry
+                ti.push_back(id[a]); tj.push_back(id[c]); tv.push_back(sacc);
+            }
+        }
+        ntot += b.n_total;
+    }
+    build_symcsc(n, ti, tj, tv, ctx->A);
+    ctx->info.n_nodes = n; ctx->info.n_elems_total = ntot; ctx->info.rows_compact = row;
+    ctx->info.nnz_A = (int64_t)ctx->A.idx.size();
+    return ADMM_OK;
+}
+
+int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
+    const int threads = std::max(1, omp_get_max_threads());
+    ctx->info.host_threads = threads;
+    if (!reuse_symbolic) {
+        std::vector<double> xyz(ctx->x);
+        analyze(ctx->A, xyz.data(), ctx->leaf_size, ctx->F);
+    }
+    int err = factorize(ctx->A, ctx->F, threads);
+    if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
+    Factor &F = ctx->F;
+    ctx->info.nnz_L = F.nnz_tri;
+    ctx->info.panel_bytes = (int64_t)F.panels.size() * 8;
+    ctx->info.n_supernodes = (int64_t)F.sn.size();
+    ctx->info.n_levels = (int64_t)F.levels.size();
+    ctx->info.max_super_cols = F.max_cols; ctx->info.max_super_rows = F.max_rows;
+    ctx->info.solve_contrib_rows = F.n_slots;
+    ctx->info.t_order_s = F.t_order; ctx->info.t_symbolic_s = F.t_symbolic; ctx->info.t_numeric_s = F.t_numeric;
+    return ADMM_OK;
+}
+
+// ---- device upload ----------------------------------------------------------
+template <class T> std::vector<T> permute_nodes(const std::vector<T> &h, const std::vector<int> &perm, int comps) {
+    std::vector<T> o(h.size());
+    for (size_t i = 0; i < perm.size(); ++i) for (int c = 0; c < comps; ++c) o[comps * i + c] = h[comps * (size_t)perm[i] + c];
+    return o;
+}
+
+int upload_factor(admm_hip_ctx *ctx) {
+    Factor &F = ctx->F;
+    const int ns = (int)F.sn.size();
+    std::vector<int> first(ns), ncols(ns), nrows(ns);
+    std::vector<int64_t> poff(ns), roff(ns), soff(ns);
+    for (int s = 0; s < ns; ++s) { first[s] = F.sn[s].first; ncols[s] = F.sn[s].ncols; nrows[s] = F.sn[s].nrows; poff[s] = F.sn[s].panel_off; roff[s] = F.sn[s].rows_off; soff[s] = F.sn[s].slot_off; }
+    TRY(upload(ctx, &ctx->d_panels, F.panels));
+    TRY(upload(ctx, &ctx->d_sn_first, first)); TRY(upload(ctx, &ctx->d_sn_ncols, ncols)); TRY(upload(ctx, &ctx->d_sn_nrows, nrows));
+    TRY(upload(ctx, &ctx->d_sn_panel_off, poff)); TRY(upload(ctx, &ctx->d_sn_rows_off, roff)); TRY(upload(ctx, &ctx->d_sn_slot_off, soff));
+    TRY(upload(ctx, &ctx->d_rows, F.rows));
+    TRY(upload(ctx, &ctx->d_gat_ptr, F.gat_ptr)); TRY(upload(ctx, &ctx->d_gat_slot, F.gat_slot));
+    TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
+    ctx->levels.assign(F.levels.size(), LevelDev());
+    for (size_t l = 0; l < F.levels.size(); ++l) {
+        LevelDev &L = ctx->levels[l];
+        std::vector<int> cols, ssn, stile, bsn, btile, wsn, wchunk;
+        for (int s : F.levels[l]) {
+            const Supernode &S = F.sn[s];
+            const int f = S.ncols + S.nrows;
+            if (F.gat_ptr[S.first + S.ncols] > F.gat_ptr[S.first]) for (int j = 0; j < S.ncols; ++j) cols.push_back(S.first + j);
+            const int tiles = (f + 63) / 64;
+            for (int t = 0; t < tiles; ++t) { if (S.ncols <= admm_dev::FWD_SMALL_KMAX) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
+            const int chunks = (S.ncols + admm_dev::BWD_COLS - 1) / admm_dev::BWD_COLS;
+            for (int c = 0; c < chunks; ++c) { wsn.push_back(s); wchunk.push_back(c); }
+        }
+        L.n_cols = (int)cols.size(); L.n_small = (int)ssn.size(); L.n_big = (int)bsn.size(); L.n_bwd = (int)wsn.size();
+        TRY(upload(ctx, &L.d_cols, cols));
+        TRY(upload(ctx, &L.d_small_sn, ssn)); TRY(upload(ctx, &L.d_small_tile, stile));
+        TRY(upload(ctx, &L.d_big_sn, bsn)); TRY(upload(ctx, &L.d_big_tile, btile));
+        TRY(upload(ctx, &L.d_bwd_sn, wsn)); TRY(upload(ctx, &L.d_bwd_chunk, wchunk));
+    }
+    return ADMM_OK;
+}
+
+int upload_all(admm_hip_ctx *ctx) {
+    const double t0 = now_s();
+    const int n = ctx->n_nodes;
+    const Factor &F = ctx->F;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    free_device(ctx);
+    {
+        std::vector<double> px = permute_nodes(ctx->x, F.perm, 3), pv = permute_nodes(ctx->v, F.perm, 3), pm = permute_nodes(ctx->m3, F.perm, 3);
+        TRY(upload(ctx, &ctx->d_x, px)); TRY(upload(ctx, &ctx->d_v, pv)); TRY(upload(ctx, &ctx->d_m3, pm));
+        TRY(upload(ctx, &ctx->d_xcur, px));
+        TRY(dalloc(ctx, &ctx->d_mxbar, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_y, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_w, 3 * (size_t)n));
+    }
+    TRY(upload_factor(ctx));
+    // batches: shard, sort corners, SoA upload
+    int64_t slot = 0, nloc = 0;
+    std::vector<std::vector<int>> inc(n); // per permuted node: slots
+    for (Batch &b : ctx->batches) {
+        const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
+        b.first = (int)((int64_t)b.n_total * ctx->rank / ctx->world);
+        const int end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
+        b.n_local = end - b.first;
+        const int nl = b.n_local;
+        b.slot_base = slot;
+        const bool sort_corners = (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TRI_STRAIN);
+        b.max_iter = 0;
+        if (b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK)
+            for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
+        std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0);
+        std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
+        b.corner_perm.assign((size_t)b.n_total * nn, 0);
+        for (int el = 0; el < nl; ++el) {
+            const int e = b.first + el;
+            const int *id = b.idx.data() + (size_t)e * nn;
+            int ord[4] = {0, 1, 2, 3};
+            if (sort_corners) std::stable_sort(ord, ord + nn, [&](int a, int c) { return id[a] < id[c]; });
+            for (int c = 0; c < nn; ++c) {
+                b.corner_perm[(size_t)e * nn + c] = ord[c];
+                const int pn = F.iperm[id[ord[c]]];
+                idx[(size_t)el * ist + c] = pn;
+                inc[pn].push_back((int)(slot + (int64_t)el * nn + c));
+            }
+            const double *R = &b.rest[(size_t)e * 12];
+            if (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) {
+                for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) rest[(size_t)(c + 4 * r) * nl + el] = R[ord[c] + 4 * r];
+            } else if (b.kind == ADMM_KIND_TRI_STRAIN) {
+                for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) rest[(size_t)(c + 3 * r) * nl + el] = R[ord[c] + 3 * r];
+            } else {
+                for (int i = 0; i < 12; ++i) rest[(size_t)i * nl + el] = R[i];
+            }
+            for (int p = 0; p < np; ++p) par[(size_t)p * nl + el] = b.params[(size_t)e * np + p];
+            const double w = b.weight[e];
+            w2[el] = w * w;
+            w2h2[el] = (ctx->dt * ctx->dt) * (w * w);
+            kbl[el] = b.params[(size_t)e * np] * b.measure[e];
+        }
+        TRY(upload(ctx, &b.d_idx, idx)); TRY(upload(ctx, &b.d_rest, rest)); TRY(upload(ctx, &b.d_par, par));
+        TRY(upload(ctx, &b.d_w2h2, w2h2)); TRY(upload(ctx, &b.d_kblend, kbl)); TRY(upload(ctx, &b.d_w2, w2));
+        TRY(dalloc(ctx, &b.d_u, (size_t)rows * std::max(nl, 1))); TRY(dalloc(ctx, &b.d_z, (size_t)rows * std::max(nl, 1)));
+        HIPCHK(hipMemset(b.d_u, 0, sizeof(double) * (size_t)rows * std::max(nl, 1)));
+        HIPCHK(hipMemset(b.d_z, 0, sizeof(double) * (size_t)rows * std::max(nl, 1)));
+        std::vector<double> st((size_t)4 * std::max(nl, 1), 1.0);
+        TRY(upload(ctx, &b.d_state, st));
+        TRY(dalloc(ctx, &b.d_niters, (size_t)std::max(nl, 1)));
+        HIPCHK(hipMemset(b.d_niters, 0, sizeof(int) * (size_t)std::max(nl, 1)));
+        if (b.kind == ADMM_KIND_ANCHOR) {
+            std::vector<double> tg((size_t)3 * std::max(nl, 1), 0.0); std::vector<int> ac(std::max(nl, 1), 1);
+            for (int el = 0; el < nl; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)(b.first + el) + j]; ac[el] = b.active[b.first + el]; }
+            TRY(upload(ctx, &b.d_targets, tg)); TRY(upload(ctx, &b.d_active, ac));
+        }
+        slot += (int64_t)nl * nn; nloc += nl;
+    }
+    ctx->n_fslots = slot; ctx->info.n_elems_local = nloc;
+    TRY(dalloc(ctx, &ctx->d_fslot, 3 * (size_t)std::max<int64_t>(slot, 1)));
+    HIPCHK(hipMemset(ctx->d_fslot, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slot, 1)));
+    {
+        std::vector<int64_t> ptr(n + 1, 0); std::vector<int> sl; sl.reserve(slot);
+        for (int i = 0; i < n; ++i) { ptr[i + 1] = ptr[i] + (int64_t)inc[i].size(); sl.insert(sl.end(), inc[i].begin(), inc[i].end()); }
+        TRY(upload(ctx, &ctx->d_inc_ptr, ptr)); TRY(upload(ctx, &ctx->d_inc_slot, sl));
+    }
+    if (ctx->timing) for (int i = 0; i < 8; ++i) if (!ctx->ev[i]) HIPCHK(hipEventCreate(&ctx->ev[i]));
+    HIPCHK(hipDeviceSynchronize());
+    ctx->info.t_upload_s = now_s() - t0;
+    return ADMM_OK;
+}
+
+BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
+    BatchDev d{};
+    d.n = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
+    d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
+    d.fslot = ctx->d_fslot + 3 * (size_t)b.slot_base; d.targets = b.d_targets; d.active = b.d_active;
+    return d;
+}
+
+FactorDev factor_dev(const admm_hip_ctx *ctx) {
+    FactorDev f{};
+    f.panels = ctx->d_panels; f.sn_first = ctx->d_sn_first; f.sn_ncols = ctx->d_sn_ncols; f.sn_nrows = ctx->d_sn_nrows;
+    f.sn_panel_off = ctx->d_sn_panel_off; f.sn_rows_off = ctx->d_sn_rows_off; f.sn_slot_off = ctx->d_sn_slot_off;
+    f.rows = ctx->d_rows; f.gat_ptr = ctx->d_gat_ptr; f.gat_slot = ctx->d_gat_slot;
+    return f;
+}
+
+int max_lbfgs_iters(const Batch &b) { return b.max_iter; }
+
+// local step: every batch kernel on x_cur
+int launch_local(admm_hip_ctx *ctx) {
+    using namespace admm_dev;
+    for (const Batch &b : ctx->batches) {
+        if (b.n_local == 0) continue;
+        const BatchDev d = batch_dev(ctx, b);
+        const dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
+        const double *x = ctx->d_xcur;
+        switch (b.kind) {
+        case ADMM_KIND_TET_NH:
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, ctx->stream, d, x);
+            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, ctx->stream, d, x);
+            break;
+        case ADMM_KIND_TET_STVK:
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, ctx->stream, d, x);
+            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, ctx->stream, d, x);
+            break;
+        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel, grid, block, 0, ctx->stream, d, x); break;
+        default: return fail(ctx, ADMM_ERR_UNSUPPORTED, "no kernel for kind %d", b.kind);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
+int launch_rhs(admm_hip_ctx *ctx) {
+    const int n3 = 3 * ctx->n_nodes;
+    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_inc_slot,
+                       ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, ctx->d_y);
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
+// both triangular sweeps: d_y (rhs, destroyed) -> d_xcur
+int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
+    using namespace admm_dev;
+    const FactorDev F = factor_dev(ctx);
+    const int nl = (int)ctx->levels.size();
+    for (int l = 0; l < nl; ++l) {
+        const LevelDev &L = ctx->levels[l];
+        if (L.n_cols) hipLaunchKernelGGL(solve_gather_kernel, dim3((3 * L.n_cols + 255) / 256), dim3(256), 0, ctx->stream, L.n_cols, L.d_cols, F, ctx->d_y, ctx->d_c);
+        if (L.n_small) hipLaunchKernelGGL(solve_fwd_small_kernel, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+        if (L.n_big) hipLaunchKernelGGL(solve_fwd_big_kernel, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+    }
+    if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
+    for (int l = nl - 1; l >= 0; --l) {
+        const LevelDev &L = ctx->levels[l];
+        if (L.n_bwd) hipLaunchKernelGGL(solve_bwd_kernel, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+    }
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
+int require_device(admm_hip_ctx *ctx) {
+    if (!ctx) return ADMM_ERR_ARG;
+    if (ctx->device_id < 0) return fail(ctx, ADMM_ERR_HIP, "host-only context: no GPU path available (the product has no CPU fallback)");
+    if (!ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "admm_hip_finalize has not been called");
+    return ADMM_OK;
+}
+
+} // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int admm_hip_create(admm_hip_ctx **out, int device_id) {
+    if (!out) return ADMM_ERR_ARG;
+    *out = nullptr;
+    admm_hip_ctx *ctx = new admm_hip_ctx();
+    ctx->device_id = device_id;
+    if (device_id >= 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= device_id) {
+            fprintf(stderr, "admm_hip: no HIP device %d (%s, %d devices) -- refusing to run without a GPU\n", device_id, hipGetErrorString(e), count);
+            delete ctx;
+            return ADMM_ERR_HIP;
+        }
+        if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return ADMM_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    ctx->info.device_id = device_id; ctx->info.world = 1;
+    const char *ls = getenv("ADMM_HIP_LEAF");
+    if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
+    *out = ctx;
+    return ADMM_OK;
+}
+
+void admm_hip_destroy(admm_hip_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->device_id >= 0) {
+        (void)hipSetDevice(ctx->device_id);
+        (void)hipDeviceSynchronize();
+        free_device(ctx);
+        for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char *admm_hip_last_error(const admm_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int admm_hip_set_stream(admm_hip_ctx *ctx, void *s) {
+    if (!ctx || ctx->device_id < 0) return ADMM_ERR_ARG;
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    ctx->own_stream = false;
+    ctx->stream = (hipStream_t)s;
+    if (!s) { HIPCHK(hipStreamCreate(&ctx->stream)); ctx->own_stream = true; }
+    return ADMM_OK;
+}
+
+int admm_hip_set_timestep(admm_hip_ctx *ctx, double dt) {
+    if (!ctx) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "timestep cannot change after finalize (System.hpp:40)");
+    ctx->dt = dt;
+    return ADMM_OK;
+}
+
+int admm_hip_add_nodes(admm_hip_ctx *ctx, int n_nodes, const double *x, const double *m, int *total) {
+    if (!ctx || n_nodes < 0 || (n_nodes && (!x || !m))) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "nodes cannot be added after finalize (System.hpp:60-62)");
+    ctx->x.insert(ctx->x.end(), x, x + 3 * (size_t)n_nodes);
+    ctx->m3.insert(ctx->m3.end(), m, m + 3 * (size_t)n_nodes);
+    ctx->v.resize(ctx->x.size(), 0.0);
+    ctx->n_nodes += n_nodes;
+    if (total) *total = ctx->n_nodes;
+    return ADMM_OK;
+}
+
+int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *idx, const double *params, const double *targets, int *batch) {
+    if (!ctx || n_elems < 0 || (n_elems && (!idx || !params))) return ADMM_ERR_ARG;
+    if (kind < 0 || kind >= ADMM_KIND_COUNT) return fail(ctx, ADMM_ERR_UNSUPPORTED, "force kind %d has no accelerated kernel", kind);
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "forces cannot be added after finalize");
+    Batch b; b.kind = kind; b.n_total = n_elems;
+    b.idx.assign(idx, idx + (size_t)n_elems * ADMM_KIND_NODES[kind]);
+    b.params.assign(params, params + (size_t)n_elems * ADMM_KIND_PARAMS[kind]);
+    if (kind == ADMM_KIND_ANCHOR) {
+        b.targets.assign((size_t)3 * n_elems, 0.0);
+        b.active.assign(n_elems, 1);
+        if (targets) {
+            b.moving = true;
+            std::copy(targets, targets + (size_t)3 * n_elems, b.targets.begin());
+            for (int e = 0; e < n_elems; ++e) b.active[e] = params[2 * (size_t)e + 1] != 0.0;
+        }
+    }
+    ctx->batches.push_back(std::move(b));
+    if (batch) *batch = (int)ctx->batches.size() - 1;
+    return ADMM_OK;
+}
+
+int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz) {
+    if (!ctx) return ADMM_ERR_ARG;
+    if (ctx->grav.n >= admm_dev::MAX_GRAV) return fail(ctx, ADMM_ERR_UNSUPPORTED, "at most %d explicit constant forces", admm_dev::MAX_GRAV);
+    double *g = ctx->grav.g[ctx->grav.n++];
+    g[0] = gx; g[1] = gy; g[2] = gz;
+    return ADMM_OK;
+}
+int admm_hip_set_gravity(admm_hip_ctx *ctx, int which, double gx, double gy, double gz) {
+    if (!ctx || which < 0 || which >= ctx->grav.n) return ADMM_ERR_ARG;
+    double *g = ctx->grav.g[which];
+    g[0] = gx; g[1] = gy; g[2] = gz;
+    return ADMM_OK;
+}
+
+int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "shard must be set before finalize");
+    ctx->rank = rank; ctx->world = world;
+    return ADMM_OK;
+}
+int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user) {
+    if (!ctx) return ADMM_ERR_ARG;
+    ctx->allreduce = fn; ctx->allreduce_user = user;
+    return ADMM_OK;
+}
+
+int admm_hip_finalize(admm_hip_ctx *ctx) {
+    if (!ctx) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "already finalized");
+    if (ctx->dt <= 0.0) { fprintf(stderr, "\n**Solver Error: timestep set to %gs, changing to 0.04s.\n", ctx->dt); ctx->dt = 0.04; }
+    if (ctx->n_nodes < 1 || ctx->m3.size() != ctx->x.size()) return fail(ctx, ADMM_ERR_ARG, "**Solver Error: Problem with node data!");
+    std::fill(ctx->v.begin(), ctx->v.end(), 0.0); // System.cpp:113
+    TRY(host_assemble(ctx, false));
+    TRY(host_factor(ctx, false));
+    ctx->info.rank = ctx->rank; ctx->info.world = ctx->world;
+    if (ctx->device_id >= 0) TRY(upload_all(ctx));
+    ctx->finalized = true;
+    return ADMM_OK;
+}
+
+int admm_hip_set_weights(admm_hip_ctx *ctx, int batch, const double *weights) {
+    if (!ctx || batch < 0 || batch >= (int)ctx->batches.size() || !weights) return ADMM_ERR_ARG;
+    if (!ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "set_weights before finalize");
+    Batch &b = ctx->batches[batch];
+    std::copy(weights, weights + b.n_total, b.weight.begin());
+    return ADMM_OK;
+}
+
+int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
+    if (!ctx || !ctx->finalized) return ADMM_ERR_STATE;
+    TRY(host_assemble(ctx, true));
+    TRY(host_factor(ctx, true));
+    if (ctx->device_id >= 0) {
+        HIPCHK(hipSetDevice(ctx->device_id));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (Batch &b : ctx->batches) {
+            const int nl = b.n_local;
+            std::vector<double> w2h2(std::max(nl, 1)), w2(std::max(nl, 1));
+            for (int el = 0; el < nl; ++el) { const double w = b.weight[b.first + el]; w2[el] = w * w; w2h2[el] = (ctx->dt * ctx->dt) * (w * w); }
+            if (nl) { HIPCHK(hipMemcpy(b.d_w2h2, w2h2.data(), sizeof(double) * nl, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(b.d_w2, w2.data(), sizeof(double) * nl, hipMemcpyHostToDevice)); }
+        }
+    }
+    return ADMM_OK;
+}
+
+int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets, const int32_t *active) {
+    if (!ctx || batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
+    Batch &b = ctx->batches[batch];
+    if (b.kind != ADMM_KIND_ANCHOR) return fail(ctx, ADMM_ERR_ARG, "batch %d is not an anchor batch", batch);
+    if (targets) std::copy(targets, targets + (size_t)3 * b.n_total, b.targets.begin());
+    if (active) std::copy(active, active + b.n_total, b.active.begin());
+    if (ctx->finalized && ctx->device_id >= 0 && b.n_local) {
+        HIPCHK(hipSetDevice(ctx->device_id));
+        if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, b.targets.data() + 3 * (size_t)b.first, sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        if (active) HIPCHK(hipMemcpyAsync(b.d_active, b.active.data() + b.first, sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return ADMM_OK;
+}
+
+int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
+    TRY(require_device(ctx));
+    using namespace admm_dev;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    const int n3 = 3 * ctx->n_nodes;
+    const bool tm = ctx->timing;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
+    if (tm) { HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream)); }
+    for (int it = 0; it < admm_iters; ++it) {
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+        TRY(launch_local(ctx));
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+        TRY(launch_rhs(ctx));
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+        if (ctx->world > 1) {
+            if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
+            if (ctx->allreduce(ctx->allreduce_user, ctx->d_y, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+        }
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+        TRY(launch_solve(ctx, tm ? ctx->ev[6] : nullptr));
+        if (tm) {
+            HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
+            HIPCHK(hipEventSynchronize(ctx->ev[7]));
+            float t;
+            HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3])); acc[1] += t;
+            HIPCHK(hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4])); acc[2] += t;
+            HIPCHK(hipEventElapsedTime(&t, ctx->ev[4], ctx->ev[5])); acc[3] += t;
+            HIPCHK(hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6])); acc[4] += t;
+            HIPCHK(hipEventElapsedTime(&t, ctx->ev[6], ctx->ev[7])); acc[5] += t;
+        }
+    }
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
+    HIPCHK(hipGetLastError());
+    if (tm) {
+        HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+        HIPCHK(hipEventSynchronize(ctx->ev[3]));
+        float t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1])); acc[0] = t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3])); acc[6] = t;
+        HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3])); acc[7] = t;
+        admm_hip_timing &T = ctx->last_timing;
+        T.prologue_ms = acc[0]; T.local_ms = acc[1]; T.rhs_ms = acc[2]; T.allreduce_ms = acc[3]; T.solve_fwd_ms = acc[4]; T.solve_bwd_ms = acc[5];
+        T.epilogue_ms = acc[6]; T.total_ms = acc[7]; T.iters = admm_iters;
+    }
+    return ADMM_OK;
+}
+
+int admm_hip_sync(admm_hip_ctx *ctx) {
+    TRY(require_device(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
+static int get_nodes(admm_hip_ctx *ctx, const double *dsrc, double *out) {
+    TRY(require_device(ctx));
+    HIPCHK(hipSetDevice(ctx->device_id));
+    std::vector<double> tmp(3 * (size_t)ctx->n_nodes);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dsrc, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const std::vector<int> &perm = ctx->F.perm;
+    for (int i = 0; i < ctx->n_nodes; ++i) for (int c = 0; c < 3; ++c) out[3 * (size_t)perm[i] + c] = tmp[3 * (size_t)i + c];
+    return ADMM_OK;
+}
+static int set_nodes(admm_hip_ctx *ctx, double *ddst, const double *in) {
+    TRY(require_device(ctx));
+    HIPCHK(hipSetDevice(ctx->device_id));
+    std::vector<double> tmp(3 * (size_t)ctx->n_nodes);
+    const std::vector<int> &perm = ctx->F.perm;
+    for (int i = 0; i < ctx->n_nodes; ++i) for (int c = 0; c < 3; ++c) tmp[3 * (size_t)i + c] = in[3 * (size_t)perm[i] + c];
+    HIPCHK(hipMemcpyAsync(ddst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
+int admm_hip_get_x(admm_hip_ctx *ctx, double *x) {
+    if (ctx && !ctx->finalized && x) { std::copy(ctx->x.begin(), ctx->x.end(), x); return ADMM_OK; }
+    if (ctx && ctx->finalized && ctx->device_id < 0 && x) { std::copy(ctx->x.begin(), ctx->x.end(), x); return ADMM_OK; }
+    return x ? get_nodes(ctx, ctx ? ctx->d_x : nullptr, x) : ADMM_ERR_ARG;
+}
+int admm_hip_set_x(admm_hip_ctx *ctx, const double *x) {
+    if (!ctx || !x) return ADMM_ERR_ARG;
+    std::copy(x, x + ctx->x.size(), ctx->x.begin());
+    if (!ctx->finalized || ctx->device_id < 0) return ADMM_OK;
+    return set_nodes(ctx, ctx->d_x, x);
+}
+int admm_hip_get_v(admm_hip_ctx *ctx, double *v) {
+    if (ctx && (!ctx->finalized || ctx->device_id < 0) && v) { std::copy(ctx->v.begin(), ctx->v.end(), v); return ADMM_OK; }
+    return v ? get_nodes(ctx, ctx ? ctx->d_v : nullptr, v) : ADMM_ERR_ARG;
+}
+int admm_hip_set_v(admm_hip_ctx *ctx, const double *v) {
+    if (!ctx || !v) return ADMM_ERR_ARG;
+    std::copy(v, v + ctx->v.size(), ctx->v.begin());
+    if (!ctx->finalized || ctx->device_id < 0) return ADMM_OK;
+    return set_nodes(ctx, ctx->d_v, v);
+}
+
+// SoA [rows][n] device -> element-major [n][rows] host
+static int read_soa(admm_hip_ctx *ctx, const double *d, int rows, int n, double *out) {
+    if (!out || n == 0) return ADMM_OK;
+    std::vector<double> tmp((size_t)rows * n);
+    HIPCHK(hipMemcpy(tmp.data(), d, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int e = 0; e < n; ++e) for (int r = 0; r < rows; ++r) out[(size_t)e * rows + r] = tmp[(size_t)r * n + e];
+    return ADMM_OK;
+}
+
+int admm_hip_read_local(admm_hip_ctx *ctx, int batch, double *u, double *z, double *state, int32_t *n_iters) {
+    TRY(require_device(ctx));
+    if (batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const Batch &b = ctx->batches[batch];
+    const int rows = ADMM_KIND_ROWS[b.kind];
+    TRY(read_soa(ctx, b.d_u, rows, b.n_local, u));
+    TRY(read_soa(ctx, b.d_z, rows, b.n_local, z));
+    if (state && ADMM_KIND_STATE[b.kind]) TRY(read_soa(ctx, b.d_state, 4, b.n_local, state));
+    if (state && b.kind == ADMM_KIND_ANCHOR && b.n_local) HIPCHK(hipMemcpy(state, b.d_targets, sizeof(double) * 3 * b.n_local, hipMemcpyDeviceToHost));
+    if (n_iters && b.n_local) HIPCHK(hipMemcpy(n_iters, b.d_niters, sizeof(int) * b.n_local, hipMemcpyDeviceToHost));
+    return ADMM_OK;
+}
+
+int admm_hip_write_local(admm_hip_ctx *ctx, int batch, const double *u, const double *state) {
+    TRY(require_device(ctx));
+    if (batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const Batch &b = ctx->batches[batch];
+    const int rows = ADMM_KIND_ROWS[b.kind], n = b.n_local;
+    if (u && n) {
+        std::vector<double> tmp((size_t)rows * n);
+        for (int e = 0; e < n; ++e) for (int r = 0; r < rows; ++r) tmp[(size_t)r * n + e] = u[(size_t)e * rows + r];
+        HIPCHK(hipMemcpy(b.d_u, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (state && n && ADMM_KIND_STATE[b.kind]) {
+        std::vector<double> tmp((size_t)4 * n);
+        for (int e = 0; e < n; ++e) for (int r = 0; r < 4; ++r) tmp[(size_t)r * n + e] = state[(size_t)e * 4 + r];
+        HIPCHK(hipMemcpy(b.d_state, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return ADMM_OK;
+}
+
+int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *rest, int32_t *global_idx) {
+    if (!ctx || !ctx->finalized || batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
+    const Batch &b = ctx->batches[batch];
+    if (weight) std::copy(b.weight.begin(), b.weight.end(), weight);
+    if (rest) std::copy(b.rest.begin(), b.rest.end(), rest);
+    if (global_idx) std::copy(b.global_idx.begin(), b.global_idx.end(), global_idx);
+    return ADMM_OK;
+}
+
+int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur) {
+    TRY(require_device(ctx));
+    if (!x_cur) return ADMM_ERR_ARG;
+    TRY(set_nodes(ctx, ctx->d_xcur, x_cur));
+    TRY(launch_local(ctx));
+    TRY(launch_rhs(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
+int admm_hip_solve_only(admm_hip_ctx *ctx, const double *b, double *x) {
+    TRY(require_device(ctx));
+    if (!b || !x) return ADMM_ERR_ARG;
+    TRY(set_nodes(ctx, ctx->d_y, b));
+    TRY(launch_solve(ctx, nullptr));
+    return get_nodes(ctx, ctx->d_xcur, x);
+}
+
+int admm_hip_apply_A(admm_hip_ctx *ctx, const double *x, double *y) {
+    if (!ctx || !ctx->finalized || !x || !y) return ADMM_ERR_ARG;
+    sym_apply(ctx->A, x, y);
+    return ADMM_OK;
+}
+
+// Validation hook for the CPU test-suite: evaluates the two panel sweeps of
+// factor.hpp on the host.  NOT used by admm_hip_step or any product path.
+int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *x) {
+    if (!ctx || !ctx->finalized || !b || !x) return ADMM_ERR_ARG;
+    panel_solve_host(ctx->F, b, x);
+    return ADMM_OK;
+}
+
+int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info) {
+    if (!ctx || !info) return ADMM_ERR_ARG;
+    *info = ctx->info;
+    return ADMM_OK;
+}
+
+int admm_hip_enable_timing(admm_hip_ctx *ctx, int on) {
+    if (!ctx) return ADMM_ERR_ARG;
+    ctx->timing = on != 0;
+    if (ctx->timing && ctx->device_id >= 0) { HIPCHK(hipSetDevice(ctx->device_id)); for (int i = 0; i < 8; ++i) if (!ctx->ev[i]) HIPCHK(hipEventCreate(&ctx->ev[i])); }
+    return ADMM_OK;
+}
+int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t) {
+    if (!ctx || !t) return ADMM_ERR_ARG;
+    *t = ctx->last_timing;
+    return ADMM_OK;
+}
+
+} // extern "C"

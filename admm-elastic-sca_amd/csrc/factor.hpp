@@ -1,0 +1,71 @@
+// factor.hpp -- host side of the global step: nested-dissection ordering,
+// supernodal symbolic analysis and multifrontal Cholesky of the scalar system
+//     A_s = M_s + dt^2 * sum_e w_e^2 G_e G_e^T          (n_nodes x n_nodes)
+// (the reference factors the 3n x 3n matrix A = A_s (x) I_3 with Eigen's
+// SimplicialLDLT + AMD: deps/admm-elastic-sca/src/system/System.cpp:138-140),
+// and the "panel" form of the factor the GPU triangular sweeps stream:
+//
+//   for every supernode s with columns C_s (k of them) and below-rows R_s (r):
+//       P_s = [ L_ss^-1 ; L_rs L_ss^-1 ]        ((k+r) x k, column-major)
+//   forward  (levels bottom-up):  t_s = b_s - sum of contributions into C_s
+//                                 [w_s ; c_s] = P_s t_s      (c_s -> slots)
+//   backward (levels top-down):   x_s = P_s^T [w_s ; -x(R_s)]
+//
+// Both sweeps are plain dense panel x vector products with 3 right-hand sides
+// (x,y,z of a node), no intra-supernode dependency, no atomics, fixed
+// summation order -> bitwise reproducible.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace admm_host {
+
+struct SymCSC {          // lower triangle (incl. diagonal), column-major, sorted rows
+    int n = 0;
+    std::vector<int64_t> ptr;
+    std::vector<int> idx;
+    std::vector<double> val;
+};
+
+struct Supernode {
+    int first = 0, ncols = 0, nrows = 0, parent = -1, level = 0;
+    int64_t rows_off = 0;   // into Factor::rows
+    int64_t panel_off = 0;  // into Factor::panels (doubles), ld = ncols + nrows
+    int64_t slot_off = 0;   // first contribution slot
+};
+
+struct Factor {
+    int n = 0;
+    std::vector<int> perm, iperm;          // perm[new] = old, iperm[old] = new
+    std::vector<Supernode> sn;             // postorder: children before parents
+    std::vector<int> rows;                 // concatenated R_s (new indices, ascending)
+    std::vector<double> panels;            // concatenated P_s
+    std::vector<std::vector<int>> levels;  // supernodes per level (level 0 = leaves)
+    std::vector<int64_t> gat_ptr;          // per new column: range into gat_slot
+    std::vector<int> gat_slot;             // contribution slots feeding that column, ascending supernode
+    int64_t n_slots = 0;                   // sum of nrows
+    int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
+    int max_cols = 0, max_rows = 0;
+    double t_order = 0, t_symbolic = 0, t_numeric = 0;
+};
+
+// Triplets of the lower triangle (i >= j), duplicates summed.
+void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj, const std::vector<double> &tv, SymCSC &A);
+
+// Geometric nested dissection on the graph of A using node coordinates
+// xyz[n][3]; fills perm/iperm, supernodes, rows, levels, gather lists.
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F);
+
+// Multifrontal numeric factorization; fills F.panels.  Returns 0 or a
+// non-zero code when A is not positive definite.
+int factorize(const SymCSC &A, Factor &F, int threads);
+
+// CPU evaluation of the two sweeps on the panel form (used by the CPU tests to
+// validate the factor; the product's solves run on the GPU).  b, x: [n][3] in
+// the ORIGINAL node order.
+void panel_solve_host(const Factor &F, const double *b, double *x);
+
+// y = A x for x,y [n][3]
+void sym_apply(const SymCSC &A, const double *x, double *y);
+
+} // namespace admm_host

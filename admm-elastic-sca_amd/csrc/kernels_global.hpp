@@ -1,0 +1,246 @@
+// kernels_global.hpp -- ADMM global step on the GPU (gfx950):
+//   * frame prologue / epilogue        (System.cpp:37-48, 70-72)
+//   * rhs_gather_kernel                b = M x_bar + dt^2 D^T W^2 (z - u)   (System.cpp:61)
+//   * the two triangular sweeps of the pre-factored system (System.cpp:62,
+//     Eigen SimplicialCholeskyBase::_solve) on the supernodal panel form built
+//     by factor.cpp: per elimination-tree level one gather kernel and dense
+//     panel x vector kernels with 3 right-hand sides (x,y,z of a node).
+//
+// All node-indexed vectors live in the factor's (nested-dissection) ordering,
+// so no permutation pass exists on the device; element node ids are mapped
+// once at upload.  Every reduction has a fixed order: results are bitwise
+// reproducible from run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace admm_dev {
+
+constexpr int MAX_GRAV = 4;
+struct Gravity { int n; double g[MAX_GRAV][3]; };
+
+// v += dt*g (each explicit force in order, ExplicitForce.cpp:29-39);
+// x_bar = x + dt v ; Mxbar = m x_bar ; x_cur = x_bar      (System.cpp:46-48)
+__global__ void prologue_kernel(int ndof, double dt, Gravity gr, const double *__restrict__ x, double *__restrict__ v,
+                                const double *__restrict__ m, double *__restrict__ mxbar, double *__restrict__ xcur) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndof) return;
+    const int c = i % 3;
+    double vi = v[i];
+    for (int k = 0; k < gr.n; ++k) vi += (dt * gr.g[k][c]);
+    v[i] = vi;
+    const double xb = x[i] + dt * vi;
+    mxbar[i] = m[i] * xb;
+    xcur[i] = xb;
+}
+
+// m_v = (curr_x - m_x) * (1/dt) ; m_x = curr_x             (System.cpp:70-71)
+__global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, double *__restrict__ v, const double *__restrict__ xcur) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndof) return;
+    const double xc = xcur[i];
+    v[i] = (xc - x[i]) * (1.0 / dt);
+    x[i] = xc;
+}
+
+// One lane per dof: b = base + sum over the node's incident element corners of
+// the per-corner contributions written by the local kernels (fixed order:
+// batch, element, corner).  base = M x_bar on rank 0, 0 elsewhere, so that the
+// cross-rank sum of the partial right-hand sides is the full one.
+__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr, const int *__restrict__ inc_slot,
+                                  const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_nodes) return;
+    const int node = i / 3, c = i - 3 * node;
+    double acc = 0.0;
+    const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
+    for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)inc_slot[p] + c];
+    y[i] = add_base ? (mxbar[i] + acc) : acc;
+}
+
+// ---------------------------------------------------------------------------
+// triangular sweeps
+// ---------------------------------------------------------------------------
+struct FactorDev {
+    const double *panels;
+    const int *sn_first, *sn_ncols, *sn_nrows;
+    const int64_t *sn_panel_off, *sn_rows_off, *sn_slot_off;
+    const int *rows;
+    const int64_t *gat_ptr;
+    const int *gat_slot;
+};
+
+// t = y - sum(contributions) for the columns of one level, in place.
+__global__ void solve_gather_kernel(int n_items, const int *__restrict__ cols, FactorDev F, double *__restrict__ y, const double *__restrict__ C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_items) return;
+    const int it = i / 3, c = i - 3 * it;
+    const int col = cols[it];
+    double t = y[3 * (size_t)col + c];
+    for (int64_t g = F.gat_ptr[col]; g < F.gat_ptr[col + 1]; ++g) t -= C[3 * (size_t)F.gat_slot[g] + c];
+    y[3 * (size_t)col + c] = t;
+}
+
+constexpr int FWD_SMALL_KMAX = 64;
+
+// Forward sweep, supernodes with k <= 64: one wave = one (supernode, 64-row tile);
+// lane = row of the panel; t_s staged per wave in LDS.
+__global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const int *__restrict__ item_sn, const int *__restrict__ item_tile,
+                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
+    __shared__ double ts[4][FWD_SMALL_KMAX * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    const bool live = item < n_items;
+    int s = 0, tile = 0, k = 0, r = 0, first = 0;
+    if (live) { s = item_sn[item]; tile = item_tile[item]; k = F.sn_ncols[s]; r = F.sn_nrows[s]; first = F.sn_first[s]; }
+    if (live && lane < k) {
+        const double *src = y + 3 * (size_t)(first + lane);
+        ts[wave][3 * lane] = src[0]; ts[wave][3 * lane + 1] = src[1]; ts[wave][3 * lane + 2] = src[2];
+    }
+    __syncthreads();
+    if (!live) return;
+    const int f = k + r;
+    const int i = tile * 64 + lane;
+    if (i >= f) return;
+    const double *P = F.panels + F.sn_panel_off[s] + i;
+    const int jend = (i < k) ? i + 1 : k;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    int j = 0;
+    for (; j + 4 <= jend; j += 4) {
+        const double p0 = P[(size_t)f * j], p1 = P[(size_t)f * (j + 1)], p2 = P[(size_t)f * (j + 2)], p3 = P[(size_t)f * (j + 3)];
+        const double *t = &ts[wave][3 * j];
+        a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+        a0 += p1 * t[3]; a1 += p1 * t[4]; a2 += p1 * t[5];
+        a0 += p2 * t[6]; a1 += p2 * t[7]; a2 += p2 * t[8];
+        a0 += p3 * t[9]; a1 += p3 * t[10]; a2 += p3 * t[11];
+    }
+    for (; j < jend; ++j) {
+        const double p0 = P[(size_t)f * j];
+        const double *t = &ts[wave][3 * j];
+        a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+    }
+    double *dst = (i < k) ? (W + 3 * (size_t)(first + i)) : (C + 3 * (size_t)(F.sn_slot_off[s] + (i - k)));
+    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+}
+
+// Forward sweep, supernodes with k > 64: one 1024-thread block = one
+// (supernode, 64-row tile); the 16 waves split the columns, partial sums are
+// combined through LDS in wave order.
+constexpr int FWD_BIG_KCHUNK = 2048;
+__global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_tile,
+                                                             FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
+    __shared__ double ts[FWD_BIG_KCHUNK * 3];
+    __shared__ double red[16][64 * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = item_sn[blockIdx.x], tile = item_tile[blockIdx.x];
+    const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
+    const int f = k + r;
+    const int i = tile * 64 + lane;
+    const bool row_ok = i < f;
+    const double *P = F.panels + F.sn_panel_off[s] + (row_ok ? i : 0);
+    const int jend = (i < k) ? i + 1 : k;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int c0 = 0; c0 < k; c0 += FWD_BIG_KCHUNK) {
+        const int kc = min(FWD_BIG_KCHUNK, k - c0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < 3 * kc; q += 1024) ts[q] = y[3 * (size_t)(first + c0) + q];
+        __syncthreads();
+        // the tile's rows need columns < min(k, tile_last_row+1): skip chunks beyond
+        const int per = (kc + 15) >> 4;
+        const int jb = c0 + wave * per;
+        int je = min(jb + per, c0 + kc);
+        if (row_ok) {
+            je = min(je, jend);
+            int j = jb;
+            for (; j + 4 <= je; j += 4) {
+                const double p0 = P[(size_t)f * j], p1 = P[(size_t)f * (j + 1)], p2 = P[(size_t)f * (j + 2)], p3 = P[(size_t)f * (j + 3)];
+                const double *t = &ts[3 * (j - c0)];
+                a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+                a0 += p1 * t[3]; a1 += p1 * t[4]; a2 += p1 * t[5];
+                a0 += p2 * t[6]; a1 += p2 * t[7]; a2 += p2 * t[8];
+                a0 += p3 * t[9]; a1 += p3 * t[10]; a2 += p3 * t[11];
+            }
+            for (; j < je; ++j) {
+                const double p0 = P[(size_t)f * j];
+                const double *t = &ts[3 * (j - c0)];
+                a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+            }
+        }
+    }
+    red[wave][3 * lane] = a0; red[wave][3 * lane + 1] = a1; red[wave][3 * lane + 2] = a2;
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int ln = threadIdx.x / 3, c = threadIdx.x - 3 * ln;
+        const int row = tile * 64 + ln;
+        if (row < f) {
+            double acc = red[0][3 * ln + c];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) acc += red[w][3 * ln + c];
+            double *dst = (row < k) ? (W + 3 * (size_t)(first + row)) : (C + 3 * (size_t)(F.sn_slot_off[s] + (row - k)));
+            dst[c] = acc;
+        }
+    }
+}
+
+// Backward sweep: one 256-thread block = (supernode, 16-column chunk); each
+// wave owns 4 columns; lanes stride over the rows of the panel column; the
+// vector [w_s ; -x(R_s)] is staged in LDS in row chunks.
+constexpr int BWD_COLS = 16;
+constexpr int BWD_RCHUNK = 2048;
+__global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_chunk,
+                                                        FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
+    __shared__ double vs[BWD_RCHUNK * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = item_sn[blockIdx.x], chunk = item_chunk[blockIdx.x];
+    const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
+    const int f = k + r;
+    const int *rows = F.rows + F.sn_rows_off[s];
+    const double *P = F.panels + F.sn_panel_off[s];
+    const int jc0 = chunk * BWD_COLS;           // first column of this block
+    const int jw = jc0 + wave * 4;              // first column of this wave
+    double acc[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[q][0] = 0.0; acc[q][1] = 0.0; acc[q][2] = 0.0; }
+    // rows < jc0 are never needed by this block (lower triangular diagonal block)
+    for (int r0 = jc0; r0 < f; r0 += BWD_RCHUNK) {
+        const int rc = min(BWD_RCHUNK, f - r0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < rc; q += 256) {
+            const int i = r0 + q;
+            double v0, v1, v2;
+            if (i < k) { const double *src = W + 3 * (size_t)(first + i); v0 = src[0]; v1 = src[1]; v2 = src[2]; }
+            else { const double *src = X + 3 * (size_t)rows[i - k]; v0 = -src[0]; v1 = -src[1]; v2 = -src[2]; }
+            vs[3 * q] = v0; vs[3 * q + 1] = v1; vs[3 * q + 2] = v2;
+        }
+        __syncthreads();
+        for (int q = lane; q < rc; q += 64) {
+            const int i = r0 + q;
+            const double v0 = vs[3 * q], v1 = vs[3 * q + 1], v2 = vs[3 * q + 2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = jw + c;
+                if (j < k && i >= j) {
+                    const double p = P[i + (size_t)f * j];
+                    acc[c][0] += p * v0; acc[c][1] += p * v1; acc[c][2] += p * v2;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double v = acc[c][d];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+            acc[c][d] = v;
+        }
+        const int j = jw + c;
+        if (lane == 0 && j < k) {
+            double *dst = X + 3 * (size_t)(first + j);
+            dst[0] = acc[c][0]; dst[1] = acc[c][1]; dst[2] = acc[c][2];
+        }
+    }
+}
+
+} // namespace admm_dev

@@ -1,0 +1,319 @@
+// kernels_local.hpp -- ADMM local step (Force::project for every element of a
+// batch) as one hand-written HIP kernel per material, gfx950.
+//
+// One lane = one element.  Fused into each kernel:
+//   * Dx_i = D_i x      (reference System.cpp:54 materialises a 36-rows-per-tet
+//                        vector with a serial sparse product; here the lane
+//                        gathers its nodes' x and multiplies by the rest
+//                        matrix B in registers),
+//   * project()         (SVD + prox / blend; local_math.hpp),
+//   * u_i += Dx_i - z_i,
+//   * the element's share of the global-step right-hand side,
+//       f_c = dt^2 w^2 * B(c,:) (z_i - u_i)   per corner c
+//     (reference System.cpp:61: solver_dt2_Dt_Wt_W * (curr_z - curr_u)),
+//     written to per-corner "force slots" that rhs_gather_kernel sums per node.
+//
+// Data layout (HBM, per batch; n = elements of this rank's shard):
+//   idx   int32 [n][4] (one 16-byte load per lane; corners sorted by original
+//         node id so that Dx accumulates in the same order as Eigen's
+//         column-major sparse product)
+//   rest  f64 SoA [12][n]   (B for tets, see force_init.hpp)
+//   par   f64 SoA [P][n]    (per-element constructor parameters)
+//   w2h2  f64 [n]           dt^2 * weight^2
+//   u, z  f64 SoA [rows][n]
+//   state f64 SoA [4][n]    (sigma warm start, L-BFGS init_hess)
+//   fslot f64 [n*nodes][3]  element-major per-corner contributions; staged
+//         through LDS so the 96 B per element leave the CU as full lines.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "local_math.hpp"
+
+namespace admm_dev {
+
+constexpr int LOCAL_BLOCK = 256;
+
+struct BatchDev {
+    int n;                 // local elements
+    const int *idx;        // [n][4]
+    const double *rest;    // SoA [12][n]
+    const double *par;     // SoA [P][n]
+    const double *w2h2;    // [n]
+    const double *kblend;  // [n]  stiffness * measure (blended kinds)
+    const double *w2;      // [n]  weight^2
+    double *u, *z;         // SoA [rows][n]
+    double *state;         // SoA [4][n]
+    int *n_iters;          // [n]
+    double *fslot;         // [n*nodes][3]
+    double *targets;       // anchors: [n][3]
+    const int *active;     // anchors: [n]
+};
+
+ADMM_HD Mat3 mat_add(const Mat3 &a, const Mat3 &b) {
+    Mat3 r;
+    r.m00 = a.m00 + b.m00; r.m10 = a.m10 + b.m10; r.m20 = a.m20 + b.m20;
+    r.m01 = a.m01 + b.m01; r.m11 = a.m11 + b.m11; r.m21 = a.m21 + b.m21;
+    r.m02 = a.m02 + b.m02; r.m12 = a.m12 + b.m12; r.m22 = a.m22 + b.m22;
+    return r;
+}
+
+// write a block's per-corner contributions (NV doubles per lane) through LDS
+// so that global stores are contiguous: out[(e0 + t) * NV + i]
+template <int NV>
+__device__ __forceinline__ void store_block_contiguous(double *lds, const double (&vals)[NV], double *out, int e0, int n_valid) {
+    constexpr int PAD = NV + 1;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[t * PAD + i] = vals[i];
+    __syncthreads();
+    const int total = n_valid * NV;
+    double *base = out + (size_t)e0 * NV;
+    for (int q = t; q < total; q += LOCAL_BLOCK) {
+        const int e = q / NV, i = q - e * NV;
+        base[q] = lds[e * PAD + i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tets: KIND 0 = Neo-Hookean, 1 = StVK (HyperElasticTet, TetForce.cpp:320-364),
+//       2 = LinearTetStrain (:127-153), 3 = TetVolume (:173-210)
+// ---------------------------------------------------------------------------
+template <int KIND, int M>
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
+    __shared__ double lds[LOCAL_BLOCK * 13];
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    const bool live = e < n;
+    const int ec = live ? e : n - 1;
+    double f[12];
+    {
+        const int4 id = reinterpret_cast<const int4 *>(b.idx)[ec];
+        const double *x0 = x + 3 * (size_t)id.x, *x1 = x + 3 * (size_t)id.y, *x2 = x + 3 * (size_t)id.z, *x3 = x + 3 * (size_t)id.w;
+        const double p0x = x0[0], p0y = x0[1], p0z = x0[2];
+        const double p1x = x1[0], p1y = x1[1], p1z = x1[2];
+        const double p2x = x2[0], p2y = x2[1], p2z = x2[2];
+        const double p3x = x3[0], p3y = x3[1], p3z = x3[2];
+        double B[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) B[i] = b.rest[(size_t)i * n + ec];
+        // Dx(j, r) = sum_c B(c, r) * x_c[j], accumulated from 0 in stored corner order
+        Mat3 Dx;
+#define ADMM_DX(r, px0, px1, px2, px3) (((0.0 + B[0 + 4 * r] * px0) + B[1 + 4 * r] * px1) + B[2 + 4 * r] * px2) + B[3 + 4 * r] * px3
+        Dx.m00 = ADMM_DX(0, p0x, p1x, p2x, p3x); Dx.m10 = ADMM_DX(0, p0y, p1y, p2y, p3y); Dx.m20 = ADMM_DX(0, p0z, p1z, p2z, p3z);
+        Dx.m01 = ADMM_DX(1, p0x, p1x, p2x, p3x); Dx.m11 = ADMM_DX(1, p0y, p1y, p2y, p3y); Dx.m21 = ADMM_DX(1, p0z, p1z, p2z, p3z);
+        Dx.m02 = ADMM_DX(2, p0x, p1x, p2x, p3x); Dx.m12 = ADMM_DX(2, p0y, p1y, p2y, p3y); Dx.m22 = ADMM_DX(2, p0z, p1z, p2z, p3z);
+#undef ADMM_DX
+        Mat3 u;
+        u.m00 = b.u[(size_t)0 * n + ec]; u.m10 = b.u[(size_t)1 * n + ec]; u.m20 = b.u[(size_t)2 * n + ec];
+        u.m01 = b.u[(size_t)3 * n + ec]; u.m11 = b.u[(size_t)4 * n + ec]; u.m21 = b.u[(size_t)5 * n + ec];
+        u.m02 = b.u[(size_t)6 * n + ec]; u.m12 = b.u[(size_t)7 * n + ec]; u.m22 = b.u[(size_t)8 * n + ec];
+        const Mat3 F = mat_add(Dx, u);
+        Mat3 z;
+        if (KIND <= 1) {
+            const double mu = b.par[(size_t)0 * n + ec], lambda = b.par[(size_t)1 * n + ec];
+            const int maxIter = (int)b.par[(size_t)2 * n + ec];
+            double sa = b.state[(size_t)0 * n + ec], sb = b.state[(size_t)1 * n + ec], sc = b.state[(size_t)2 * n + ec], hs = b.state[(size_t)3 * n + ec];
+            int it = 0;
+            z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it);
+            if (live) {
+                b.state[(size_t)0 * n + e] = sa; b.state[(size_t)1 * n + e] = sb; b.state[(size_t)2 * n + e] = sc; b.state[(size_t)3 * n + e] = hs;
+                b.n_iters[e] = it;
+            }
+        } else {
+            const double lmin = (KIND == 3) ? b.par[(size_t)1 * n + ec] : 0.0, lmax = (KIND == 3) ? b.par[(size_t)2 * n + ec] : 0.0;
+            const Mat3 p = project_tet_p<KIND == 3>(F, lmin, lmax);
+            const double k = b.kblend[ec], w2 = b.w2[ec];
+            const double den = w2 + k;
+            z.m00 = (k * p.m00 + w2 * F.m00) / den; z.m10 = (k * p.m10 + w2 * F.m10) / den; z.m20 = (k * p.m20 + w2 * F.m20) / den;
+            z.m01 = (k * p.m01 + w2 * F.m01) / den; z.m11 = (k * p.m11 + w2 * F.m11) / den; z.m21 = (k * p.m21 + w2 * F.m21) / den;
+            z.m02 = (k * p.m02 + w2 * F.m02) / den; z.m12 = (k * p.m12 + w2 * F.m12) / den; z.m22 = (k * p.m22 + w2 * F.m22) / den;
+        }
+        // u += Dx - z ; q = z - u
+        Mat3 q;
+#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (live) { b.u[(size_t)row * n + e] = un; b.z[(size_t)row * n + e] = z.mm; } }
+        ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
+#undef ADMM_UZ
+        const double s = b.w2h2[ec];
+        // f_c[j] = s * sum_r B(c, r) q(j, r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f[3 * c + 0] = s * ((B[c] * q.m00 + B[c + 4] * q.m01) + B[c + 8] * q.m02);
+            f[3 * c + 1] = s * ((B[c] * q.m10 + B[c + 4] * q.m11) + B[c + 8] * q.m12);
+            f[3 * c + 2] = s * ((B[c] * q.m20 + B[c + 4] * q.m21) + B[c + 8] * q.m22);
+        }
+    }
+    const int e0 = blockIdx.x * LOCAL_BLOCK;
+    const int n_valid = min(LOCAL_BLOCK, n - e0);
+    store_block_contiguous<12>(lds, f, b.fslot, e0, n_valid);
+}
+
+// ---------------------------------------------------------------------------
+// StaticAnchor / MovingAnchor, AnchorForce.cpp:46-55, 71-89
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    if (e >= n) return;
+    const int id = b.idx[e];
+    const double s = b.w2h2[e];
+    const bool act = b.active[e] != 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
+        const double u = b.u[(size_t)j * n + e];
+        double zi;
+        if (act) zi = b.targets[3 * (size_t)e + j];
+        else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
+        const double un = u + (dx - zi);
+        b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
+        b.fslot[3 * (size_t)e + j] = s * (zi - un);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Spring, Force.cpp:52-71   (rows: x_a - x_b)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b, const double *__restrict__ x) {
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    if (e >= n) return;
+    const int ia = b.idx[2 * (size_t)e], ib = b.idx[2 * (size_t)e + 1];
+    const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e], rest_length = b.rest[e];
+    double dx[3], u[3], d[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double xa = x[3 * (size_t)ia + j], xb = x[3 * (size_t)ib + j];
+        // column-ascending accumulation of (+1) x_a + (-1) x_b
+        dx[j] = (ia < ib) ? ((0.0 + 1.0 * xa) + -1.0 * xb) : ((0.0 + -1.0 * xb) + 1.0 * xa);
+        u[j] = b.u[(size_t)j * n + e];
+        d[j] = dx[j] + u[j];
+    }
+    const double nrm = sqrt(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2]));
+    const double c = 1.0 / (w2 + st);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double dn = d[j] / nrm;
+        if (nrm <= 0.0) dn = 0.0;
+        const double p = rest_length * dn;
+        const double zi = c * (st * p + w2 * d[j]);
+        const double un = u[j] + (dx[j] - zi);
+        b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
+        const double f = s * (zi - un);
+        b.fslot[3 * (2 * (size_t)e) + j] = f;
+        b.fslot[3 * (2 * (size_t)e + 1) + j] = -f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BendForce, BendForce.cpp:131-161   rows (x0-x2, x3-x2, x1-x2)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) {
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    if (e >= n) return;
+    const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
+    const double a0 = b.rest[(size_t)0 * n + e], a1 = b.rest[(size_t)1 * n + e], a3 = b.rest[(size_t)3 * n + e];
+    const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e];
+    const double den = a0 * a0 + a3 * a3 + a1 * a1;
+    const double cc = 1.0 / (w2 + st);
+    const int plus[3] = {id.x, id.w, id.y};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double x2 = x[3 * (size_t)id.z + j];
+        double dx[3], u[3], d[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double xp = x[3 * (size_t)plus[r] + j];
+            dx[r] = (plus[r] < id.z) ? ((0.0 + 1.0 * xp) + -1.0 * x2) : ((0.0 + -1.0 * x2) + 1.0 * xp);
+            u[r] = b.u[(size_t)(3 * r + j) * n + e];
+            d[r] = dx[r] + u[r];
+        }
+        const double lam = 2.0 * (a0 * d[0] + a3 * d[1] + a1 * d[2]) / den;
+        const double p0 = d[0] - 0.5 * a0 * lam, p1 = d[1] - 0.5 * a3 * lam, p2 = d[2] - 0.5 * a1 * lam;
+        const double pr[3] = {p0, p1, p2};
+        double f[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double zi = cc * (st * pr[r] + w2 * d[r]);
+            const double un = u[r] + (dx[r] - zi);
+            b.u[(size_t)(3 * r + j) * n + e] = un; b.z[(size_t)(3 * r + j) * n + e] = zi;
+            f[r] = s * (zi - un);
+        }
+        // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
+        b.fslot[3 * (4 * (size_t)e + 0) + j] = f[0];
+        b.fslot[3 * (4 * (size_t)e + 1) + j] = f[2];
+        b.fslot[3 * (4 * (size_t)e + 2) + j] = -((f[0] + f[1]) + f[2]);
+        b.fslot[3 * (4 * (size_t)e + 3) + j] = f[1];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LimitedTriangleStrain, TriangleForce.cpp:78-113.
+// T = U(:,0:2) V^T of the 3x2 SVD is the polar factor of F; computed here
+// through the 2x2 symmetric eigen-decomposition of F^T F (closed form), which
+// agrees with the reference's QR-preconditioned Jacobi SVD to rounding
+// (tests state the tolerance; this kernel is not bit-exact by construction).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) {
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    if (e >= n) return;
+    const int i0 = b.idx[4 * (size_t)e], i1 = b.idx[4 * (size_t)e + 1], i2 = b.idx[4 * (size_t)e + 2];
+    double B[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) B[i] = b.rest[(size_t)i * n + e];
+    double dx[6], u[6], d[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double xa = x[3 * (size_t)i0 + j], xb = x[3 * (size_t)i1 + j], xc = x[3 * (size_t)i2 + j];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            dx[3 * r + j] = ((0.0 + B[0 + 3 * r] * xa) + B[1 + 3 * r] * xb) + B[2 + 3 * r] * xc;
+            u[3 * r + j] = b.u[(size_t)(3 * r + j) * n + e];
+            d[3 * r + j] = dx[3 * r + j] + u[3 * r + j];
+        }
+    }
+    // C = F^T F (2x2), polar factor T = F C^{-1/2}
+    const double c00 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double c01 = d[0] * d[3] + d[1] * d[4] + d[2] * d[5];
+    const double c11 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+    const double detC = c00 * c11 - c01 * c01;
+    double T[6];
+    {
+        // sqrt of SPD 2x2: S = (C + sqrt(det) I) / sqrt(tr + 2 sqrt(det)); T = F S^-1
+        const double sd = sqrt(detC > 0.0 ? detC : 0.0);
+        const double tr = c00 + c11;
+        const double den = sqrt(tr + 2.0 * sd);
+        const double s00 = (c00 + sd) / den, s01 = c01 / den, s11 = (c11 + sd) / den;
+        const double ds = s00 * s11 - s01 * s01;
+        const double i00 = s11 / ds, i01 = -s01 / ds, i11 = s00 / ds;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { T[j] = d[j] * i00 + d[3 + j] * i01; T[3 + j] = d[j] * i01 + d[3 + j] * i11; }
+    }
+    const double k = b.kblend[e], w2 = b.w2[e], s = b.w2h2[e];
+    double zi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
+    if (b.par[(size_t)3 * n + e] != 0.0) {
+        const double lmin = b.par[(size_t)1 * n + e], lmax = b.par[(size_t)2 * n + e];
+        const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
+        const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
+        const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
+        if (l0 < lmin) { const double sc = lmin / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+        if (l1 < lmin) { const double sc = lmin / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+        if (l0 > lmax) { const double sc = lmax / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+        if (l1 > lmax) { const double sc = lmax / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+    }
+    double q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double un = u[i] + (dx[i] - zi[i]);
+        b.u[(size_t)i * n + e] = un; b.z[(size_t)i * n + e] = zi[i];
+        q[i] = zi[i] - un;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b.fslot[3 * (3 * (size_t)e + c) + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
+}
+
+} // namespace admm_dev

@@ -1,0 +1,504 @@
+// local_math.hpp -- per-element arithmetic of the ADMM local step, written for
+// one GPU lane per element with everything in registers (no arrays indexed at
+// run time, every loop over matrix entries unrolled at compile time).
+//
+// Built with -ffp-contract=off: the operation order below is the order the
+// reference's Eigen/cppoptlib expressions evaluate in on x86-64 SSE2 (no FMA),
+// so every kernel that does not call log() is bit-identical to the reference;
+// the Neo-Hookean prox differs only through OCML's log() vs glibc's (<= 1 ulp).
+//
+// Reference (under /root/reference):
+//   CORE = deps/admm-elastic-sca/src/system
+//   OPT  = deps/admm-elastic-sca/deps/cppoptlib/include/cppoptlib
+//   EIG  = deps/admm-elastic-sca/deps/Eigen3/Eigen/src
+#pragma once
+
+#include <float.h>
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define ADMM_HD __host__ __device__ __forceinline__
+#else
+#define ADMM_HD inline
+#endif
+
+namespace admm_dev {
+
+// libstdc++ std::min / std::max (second argument wins only on strict compare;
+// this fixes what happens with NaNs exactly like the reference build)
+ADMM_HD double smin(double a, double b) { return (b < a) ? b : a; }
+ADMM_HD double smax(double a, double b) { return (a < b) ? b : a; }
+
+constexpr double kFltMax = 3.40282346638528859811704183484516925e+38; // (double)FLT_MAX
+
+// A 3x3 matrix as nine named registers, column-major names mRC.
+struct Mat3 {
+    double m00, m10, m20, m01, m11, m21, m02, m12, m22;
+};
+
+template <int R, int C> ADMM_HD double &at(Mat3 &m) {
+    if (R == 0 && C == 0) return m.m00; if (R == 1 && C == 0) return m.m10; if (R == 2 && C == 0) return m.m20;
+    if (R == 0 && C == 1) return m.m01; if (R == 1 && C == 1) return m.m11; if (R == 2 && C == 1) return m.m21;
+    if (R == 0 && C == 2) return m.m02; if (R == 1 && C == 2) return m.m12; return m.m22;
+}
+template <int R, int C> ADMM_HD double at(const Mat3 &m) { return at<R, C>(const_cast<Mat3 &>(m)); }
+
+ADMM_HD Mat3 identity3() { Mat3 m; m.m00 = 1; m.m10 = 0; m.m20 = 0; m.m01 = 0; m.m11 = 1; m.m21 = 0; m.m02 = 0; m.m12 = 0; m.m22 = 1; return m; }
+
+// Matrix3d::determinant(), EIG/LU/Determinant.h:18-23,61-68
+ADMM_HD double det3(const Mat3 &m) {
+    double h0 = m.m00 * (m.m11 * m.m22 - m.m12 * m.m21);
+    double h1 = m.m01 * (m.m10 * m.m22 - m.m12 * m.m20);
+    double h2 = m.m02 * (m.m10 * m.m21 - m.m11 * m.m20);
+    return h0 - h1 + h2;
+}
+
+// internal::apply_rotation_in_the_plane on one (x, y) pair, EIG/Jacobi/Jacobi.h:302-430
+ADMM_HD void rot2(double &x, double &y, double c, double s) {
+    double xi = x, yi = y;
+    x = c * xi + s * yi;
+    y = -s * xi + c * yi;
+}
+// rows P,Q of m (applyOnTheLeft)
+template <int P, int Q> ADMM_HD void rot_rows(Mat3 &m, double c, double s) {
+    if (c == 1.0 && s == 0.0) return;
+    rot2(at<P, 0>(m), at<Q, 0>(m), c, s);
+    rot2(at<P, 1>(m), at<Q, 1>(m), c, s);
+    rot2(at<P, 2>(m), at<Q, 2>(m), c, s);
+}
+// columns P,Q of m (applyOnTheRight with the transposed rotation already folded into s)
+template <int P, int Q> ADMM_HD void rot_cols(Mat3 &m, double c, double s) {
+    if (c == 1.0 && s == 0.0) return;
+    rot2(at<0, P>(m), at<0, Q>(m), c, s);
+    rot2(at<1, P>(m), at<1, Q>(m), c, s);
+    rot2(at<2, P>(m), at<2, Q>(m), c, s);
+}
+
+// numext::hypot, EIG/Core/MathFunctions.h:284-302
+ADMM_HD double eig_hypot(double x, double y) {
+    double ax = fabs(x), ay = fabs(y);
+    double p = smax(ax, ay);
+    if (p == 0.0) return 0.0;
+    double q = smin(ax, ay);
+    double qp = q / p;
+    return p * sqrt(1.0 + qp * qp);
+}
+
+// One (p,q) step of the two-sided Jacobi sweep: threshold test,
+// real_2x2_jacobi_svd (EIG/SVD/JacobiSVD.h:415-443) with
+// JacobiRotation::makeJacobi (EIG/Jacobi/Jacobi.h:80-110), and the four
+// rotation applications of JacobiSVD::compute (JacobiSVD.h:873-897).
+template <int P, int Q> ADMM_HD bool jacobi_pq(Mat3 &W, Mat3 &U, Mat3 &V) {
+    const double precision = 2.0 * DBL_EPSILON;
+    const double considerAsZero = 2.0 * 4.9406564584124654e-324;
+    double wpp = at<P, P>(W), wqq = at<Q, Q>(W), wpq = at<P, Q>(W), wqp = at<Q, P>(W);
+    double threshold = smax(considerAsZero, precision * smax(fabs(wpp), fabs(wqq)));
+    if (!(fabs(wpq) > threshold || fabs(wqp) > threshold)) return false;
+    double m00 = wpp, m01 = wpq, m10 = wqp, m11 = wqq;
+    double c1, s1;
+    double t = m00 + m11, d = m10 - m01;
+    if (t == 0.0) { c1 = 0.0; s1 = d > 0.0 ? 1.0 : -1.0; }
+    else {
+        double t2d2 = eig_hypot(t, d);
+        c1 = fabs(t) / t2d2;
+        s1 = d / t2d2;
+        if (t < 0.0) s1 = -s1;
+    }
+    if (!(c1 == 1.0 && s1 == 0.0)) { rot2(m00, m10, c1, s1); rot2(m01, m11, c1, s1); }
+    double rc, rs;
+    if (m01 == 0.0) { rc = 1.0; rs = 0.0; }
+    else {
+        double tau = (m00 - m11) / (2.0 * fabs(m01));
+        double w = sqrt(tau * tau + 1.0);
+        double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double sign_t = tt > 0.0 ? 1.0 : -1.0;
+        double n = 1.0 / sqrt(tt * tt + 1.0);
+        rs = -sign_t * (m01 / fabs(m01)) * fabs(tt) * n;
+        rc = n;
+    }
+    double os = -rs;
+    double lc = c1 * rc - s1 * os;
+    double ls = c1 * os + s1 * rc;
+    rot_rows<P, Q>(W, lc, ls);
+    rot_cols<P, Q>(U, lc, ls);
+    rot_cols<P, Q>(W, rc, -rs);
+    rot_cols<P, Q>(V, rc, -rs);
+    return true;
+}
+
+template <int A, int B> ADMM_HD void swap_cols(Mat3 &m) {
+    double t;
+    t = at<0, A>(m); at<0, A>(m) = at<0, B>(m); at<0, B>(m) = t;
+    t = at<1, A>(m); at<1, A>(m) = at<1, B>(m); at<1, B>(m) = t;
+    t = at<2, A>(m); at<2, A>(m) = at<2, B>(m); at<2, B>(m) = t;
+}
+template <int C> ADMM_HD void scale_col(Mat3 &m, double f) { at<0, C>(m) *= f; at<1, C>(m) *= f; at<2, C>(m) *= f; }
+
+// Eigen::JacobiSVD<Matrix3d>(F, ComputeFullU|ComputeFullV), EIG/SVD/JacobiSVD.h:824-933
+ADMM_HD void svd3(const Mat3 &F, Mat3 &U, double &s0, double &s1, double &s2, Mat3 &V) {
+    double scale = fabs(F.m00);
+    scale = smax(scale, fabs(F.m10)); scale = smax(scale, fabs(F.m20));
+    scale = smax(scale, fabs(F.m01)); scale = smax(scale, fabs(F.m11)); scale = smax(scale, fabs(F.m21));
+    scale = smax(scale, fabs(F.m02)); scale = smax(scale, fabs(F.m12)); scale = smax(scale, fabs(F.m22));
+    if (scale == 0.0) scale = 1.0;
+    Mat3 W;
+    W.m00 = F.m00 / scale; W.m10 = F.m10 / scale; W.m20 = F.m20 / scale;
+    W.m01 = F.m01 / scale; W.m11 = F.m11 / scale; W.m21 = F.m21 / scale;
+    W.m02 = F.m02 / scale; W.m12 = F.m12 / scale; W.m22 = F.m22 / scale;
+    U = identity3(); V = identity3();
+    bool finished = false;
+    while (!finished) {
+        bool a = jacobi_pq<1, 0>(W, U, V);
+        bool b = jacobi_pq<2, 0>(W, U, V);
+        bool c = jacobi_pq<2, 1>(W, U, V);
+        finished = !(a || b || c);
+    }
+    double a0 = fabs(W.m00), a1 = fabs(W.m11), a2 = fabs(W.m22);
+    if (a0 != 0.0) scale_col<0>(U, W.m00 / a0);
+    if (a1 != 0.0) scale_col<1>(U, W.m11 / a1);
+    if (a2 != 0.0) scale_col<2>(U, W.m22 / a2);
+    s0 = a0; s1 = a1; s2 = a2;
+    // descending sort, first maximum wins (EIG/SVD/JacobiSVD.h:910-926); a zero
+    // maximum ends the loop
+    {
+        int pos = 0; double mx = s0;
+        if (s1 > mx) { mx = s1; pos = 1; }
+        if (s2 > mx) { mx = s2; pos = 2; }
+        if (mx != 0.0) {
+            if (pos == 1) { double t = s0; s0 = s1; s1 = t; swap_cols<0, 1>(U); swap_cols<0, 1>(V); }
+            else if (pos == 2) { double t = s0; s0 = s2; s2 = t; swap_cols<0, 2>(U); swap_cols<0, 2>(V); }
+            if (s2 > s1) { double t = s1; s1 = s2; s2 = t; swap_cols<1, 2>(U); swap_cols<1, 2>(V); }
+        }
+    }
+    s0 *= scale; s1 *= scale; s2 *= scale;
+}
+
+// helper::oriented_svd, CORE/TetForce.cpp:80-102 (Vt returned as V with the
+// sign fix applied to V's column 2, i.e. Vt's row 2)
+ADMM_HD void oriented_svd(const Mat3 &F, double &s0, double &s1, double &s2, Mat3 &U, Mat3 &V) {
+    svd3(F, U, s0, s1, s2, V);
+    if (det3(U) < 0.0) { U.m02 = -U.m02; U.m12 = -U.m12; U.m22 = -U.m22; s2 *= -1.0; }
+    // Vt.determinant() on the transposed matrix: same formula with indices swapped
+    Mat3 Vt; Vt.m00 = V.m00; Vt.m01 = V.m10; Vt.m02 = V.m20; Vt.m10 = V.m01; Vt.m11 = V.m11; Vt.m12 = V.m21; Vt.m20 = V.m02; Vt.m21 = V.m12; Vt.m22 = V.m22;
+    if (det3(Vt) < 0.0) { V.m02 = -V.m02; V.m12 = -V.m12; V.m22 = -V.m22; s2 *= -1.0; }
+}
+
+// U * diag(s) * V^T with Eigen's coefficient order ((p0+p1)+p2), p_k = (U(i,k)*s_k)*V(j,k)
+ADMM_HD Mat3 recompose(const Mat3 &U, double s0, double s1, double s2, const Mat3 &V) {
+    Mat3 r;
+#define ADMM_RC(i, j) ((at<i, 0>(U) * s0) * at<j, 0>(V) + (at<i, 1>(U) * s1) * at<j, 1>(V)) + (at<i, 2>(U) * s2) * at<j, 2>(V)
+    r.m00 = ADMM_RC(0, 0); r.m10 = ADMM_RC(1, 0); r.m20 = ADMM_RC(2, 0);
+    r.m01 = ADMM_RC(0, 1); r.m11 = ADMM_RC(1, 1); r.m21 = ADMM_RC(2, 1);
+    r.m02 = ADMM_RC(0, 2); r.m12 = ADMM_RC(1, 2); r.m22 = ADMM_RC(2, 2);
+#undef ADMM_RC
+    return r;
+}
+
+struct V3 { double a, b, c; };
+ADMM_HD double dotd(const V3 &x, const V3 &y) { return (x.a * y.a + x.b * y.b) + x.c * y.c; } // dynamic-size order
+ADMM_HD double absmax(const V3 &x) { double r = fabs(x.a); r = smax(r, fabs(x.b)); r = smax(r, fabs(x.c)); return r; }
+
+// ---- prox objective: NHProx / StVKProx, CORE/TetForce.cpp:216-297 ----------
+template <int TYPE> struct Prox {
+    double mu, lambda, k;
+    V3 s0;
+
+    ADMM_HD double value(const V3 &x) const {
+        if (x.a < 0.0 || x.b < 0.0 || x.c < 0.0) return kFltMax;
+        double da = x.a - s0.a, db = x.b - s0.b, dc = x.c - s0.c;
+        if (TYPE == 0) {
+            double Sig_det = (x.a * x.b * x.c);
+            double I_1 = x.a * x.a + x.b * x.b + x.c * x.c;
+            double I_3 = Sig_det * Sig_det;
+            double log_I3 = log(I_3);
+            double t1 = 0.5 * mu * (I_1 - log_I3 - 3.0);
+            double t2 = 0.125 * lambda * log_I3 * log_I3;
+            double r = t1 + t2;
+            double r2 = (k * 0.5) * ((da * da + db * db) + dc * dc);
+            return (1.0 * r + r2);
+        } else {
+            double ea = 0.5 * (x.a * x.a - 1.0), eb = 0.5 * (x.b * x.b - 1.0), ec = 0.5 * (x.c * x.c - 1.0);
+            double tr = (ea + eb) + ec;
+            double st_tr2 = tr * tr;
+            double dd = ea * ea + (eb * eb + ec * ec);
+            double r = (mu * dd + (lambda * 0.5 * st_tr2));
+            double r2 = (k * 0.5) * (da * da + (db * db + dc * dc));
+            return (r + r2);
+        }
+    }
+    ADMM_HD V3 gradient(const V3 &x) const {
+        V3 g;
+        if (TYPE == 0) {
+            double detSigma = x.a * x.b * x.c;
+            if (detSigma <= 0.0) { g.a = g.b = g.c = 1.0 * kFltMax; return g; }
+            double ia = 1.0 / x.a, ib = 1.0 / x.b, ic = 1.0 / x.c;
+            double ll = lambda * log(detSigma);
+            g.a = 1.0 * (mu * (x.a - ia) + ll * ia) + k * (x.a - s0.a);
+            g.b = 1.0 * (mu * (x.b - ib) + ll * ib) + k * (x.b - s0.b);
+            g.c = 1.0 * (mu * (x.c - ic) + ll * ic) + k * (x.c - s0.c);
+        } else {
+            double xx = (x.a * x.a + x.b * x.b) + x.c * x.c;
+            double c2 = 0.5 * lambda * (xx - 3.0);
+            g.a = mu * x.a * (x.a * x.a - 1.0) + c2 * x.a + k * (x.a - s0.a);
+            g.b = mu * x.b * (x.b * x.b - 1.0) + c2 * x.b + k * (x.b - s0.b);
+            g.c = mu * x.c * (x.c * x.c - 1.0) + c2 * x.c + k * (x.c - s0.c);
+        }
+        return g;
+    }
+};
+
+// ---- MoreThuente::cstep, OPT/linesearch/morethuente.h:169-308 ---------------
+ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
+                      double fp, double dp, bool &brackt, double stpmin, double stpmax, int &info) {
+    info = 0;
+    bool bound = false;
+    if ((brackt & ((stp <= smin(stx, sty)) | (stp >= smax(stx, sty)))) | (dx * (stp - stx) >= 0.0) | (stpmax < stpmin)) return;
+    double sgnd = dp * (dx / fabs(dx));
+    double stpf = 0, stpc = 0, stpq = 0;
+    if (fp > fx) {
+        info = 1; bound = true;
+        double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+        double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma = -gamma;
+        double p = (gamma - dx) + theta;
+        double q = ((gamma - dx) + gamma) + dp;
+        double r = p / q;
+        stpc = stx + r * (stp - stx);
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.) * (stp - stx);
+        if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
+        else stpf = stpc + (stpq - stpc) / 2;
+        brackt = true;
+    } else if (sgnd < 0.0) {
+        info = 2; bound = false;
+        double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma = -gamma;
+        double p = (gamma - dp) + theta;
+        double q = ((gamma - dp) + gamma) + dx;
+        double r = p / q;
+        stpc = stp + r * (stx - stp);
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+        else stpf = stpq;
+        brackt = true;
+    } else if (fabs(dp) < fabs(dx)) {
+        info = 3; bound = true;
+        double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt(smax(0., (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        double p = (gamma - dp) + theta;
+        double q = (gamma + (dx - dp)) + gamma;
+        double r = p / q;
+        if ((r < 0.0) & (gamma != 0.0)) stpc = stp + r * (stx - stp);
+        else if (stp > stx) stpc = stpmax;
+        else stpc = stpmin;
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (brackt) { if (fabs(stp - stpc) < fabs(stp - stpq)) stpf = stpc; else stpf = stpq; }
+        else { if (fabs(stp - stpc) > fabs(stp - stpq)) stpf = stpc; else stpf = stpq; }
+    } else {
+        info = 4; bound = false;
+        if (brackt) {
+            double theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
+            double s = smax(theta, smax(dy, dp));
+            double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            double p = (gamma - dp) + theta;
+            double q = ((gamma - dp) + gamma) + dy;
+            double r = p / q;
+            stpc = stp + r * (sty - stp);
+            stpf = stpc;
+        } else if (stp > stx) stpf = stpmax;
+        else stpf = stpmin;
+    }
+    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
+    else {
+        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stpf = smin(stpmax, stpf);
+    stpf = smax(stpmin, stpf);
+    stp = stpf;
+    if (brackt & bound) {
+        if (sty > stx) stp = smin(stx + 0.66 * (sty - stx), stp);
+        else stp = smax(stx + 0.66 * (sty - stx), stp);
+    }
+}
+
+// ---- MoreThuente::linesearch + cvsrch, morethuente.h:25-167 ------------------
+// x: base point, s: direction (= -q).  Returns the step length.
+template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, const V3 &s, double alpha_init) {
+    double stp = alpha_init;
+    double f = prob.value(x);
+    V3 g = prob.gradient(x);
+    int info = 0, infoc = 1;
+    const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
+    const int maxfev = 20;
+    int nfev = 0;
+    double dginit = dotd(g, s);
+    if (dginit >= 0.0) return stp;
+    bool brackt = false, stage1 = true;
+    double finit = f, dgtest = ftol * dginit;
+    double width = stpmax - stpmin, width1 = 2 * width;
+    double stx = 0.0, fx = finit, dgx = dginit, sty = 0.0, fy = finit, dgy = dginit;
+    double stmin = 0.0, stmax = 0.0;
+    for (;;) {
+        if (brackt) { stmin = smin(stx, sty); stmax = smax(stx, sty); }
+        else { stmin = stx; stmax = stp + xtrapf * (stp - stx); }
+        stp = smax(stp, stpmin);
+        stp = smin(stp, stpmax);
+        if ((brackt && ((stp <= stmin) | (stp >= stmax))) | (nfev >= maxfev - 1) | (infoc == 0) | (brackt & (stmax - stmin <= xtol * stmax))) stp = stx;
+        V3 xn; xn.a = x.a + stp * s.a; xn.b = x.b + stp * s.b; xn.c = x.c + stp * s.c;
+        f = prob.value(xn);
+        g = prob.gradient(xn);
+        nfev++;
+        double dg = dotd(g, s);
+        double ftest1 = finit + stp * dgtest;
+        if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
+        if ((stp == stpmax) & (f <= ftest1) & (dg <= dgtest)) info = 5;
+        if ((stp == stpmin) & ((f > ftest1) | (dg >= dgtest))) info = 4;
+        if (nfev >= maxfev) info = 3;
+        if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+        if ((f <= ftest1) & (fabs(dg) <= gtol * (-dginit))) info = 1;
+        if (info != 0) return stp;
+        if (stage1 & (f <= ftest1) & (dg >= smin(ftol, gtol) * dginit)) stage1 = false;
+        if (stage1 & (f <= fx) & (f > ftest1)) {
+            double fm = f - stp * dgtest;
+            double fxm = fx - stx * dgtest;
+            double fym = fy - sty * dgtest;
+            double dgm = dg - dgtest;
+            double dgxm = dgx - dgtest;
+            double dgym = dgy - dgtest;
+            mt_cstep(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, brackt, stmin, stmax, infoc);
+            fx = fxm + stx * dgtest;
+            fy = fym + sty * dgtest;
+            dgx = dgxm + dgtest;
+            dgy = dgym + dgtest;
+        } else {
+            mt_cstep(stx, fx, dgx, sty, fy, dgy, stp, f, dg, brackt, stmin, stmax, infoc);
+        }
+        if (brackt) {
+            if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+            width1 = width;
+            width = fabs(sty - stx);
+        }
+    }
+}
+
+// ---- cppoptlib::lbfgssolver<double>::minimize, OPT/solver/lbfgssolver.h:43-144
+// M = compile-time history capacity (>= min(maxIter,10)); history lives in
+// registers, run-time positions are resolved by unrolled selects.
+template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int maxIter, double gradTol, double &init_hess) {
+    const int m_ = maxIter < 10 ? maxIter : 10;
+    const double eps_g = gradTol, eps_x = 1e-8;
+    V3 s[M], y[M];
+    double alpha[M], rho[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { s[i].a = s[i].b = s[i].c = 0.0; y[i].a = y[i].b = y[i].c = 0.0; alpha[i] = 0.0; rho[i] = 0.0; }
+    V3 grad = prob.gradient(x0);
+    double gamma_k = init_hess;
+    double alpha_init = smin(1.0, 1.0 / absmax(grad));
+    int globIter = 0;
+    int maxiter = maxIter;
+    double new_hess_guess = 1.0;
+    for (int k = 0; k < maxiter; k++) {
+        V3 x_old = x0, grad_old = grad, q = grad;
+        globIter++;
+        const int iter = m_ < k ? m_ : k;
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) {
+            if (i < iter) {
+                rho[i] = 1.0 / dotd(s[i], y[i]);
+                alpha[i] = rho[i] * dotd(s[i], q);
+                q.a = q.a - alpha[i] * y[i].a; q.b = q.b - alpha[i] * y[i].b; q.c = q.c - alpha[i] * y[i].c;
+            }
+        }
+        q.a = gamma_k * q.a; q.b = gamma_k * q.b; q.c = gamma_k * q.c;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i < iter) {
+                double beta = rho[i] * dotd(q, y[i]);
+                double ab = alpha[i] - beta;
+                q.a = q.a + ab * s[i].a; q.b = q.b + ab * s[i].b; q.c = q.c + ab * s[i].c;
+            }
+        }
+        double dir = dotd(q, grad);
+        if (dir < 1e-4) {
+            q = grad;
+            maxiter -= k;
+            k = 0;
+            alpha_init = smin(1.0, 1.0 / absmax(grad));
+        }
+        V3 mq; mq.a = -q.a; mq.b = -q.b; mq.c = -q.c;
+        const double rate = mt_linesearch(prob, x0, mq, alpha_init);
+        x0.a = x0.a - rate * q.a; x0.b = x0.b - rate * q.b; x0.c = x0.c - rate * q.c;
+        V3 dxx; dxx.a = x_old.a - x0.a; dxx.b = x_old.b - x0.b; dxx.c = x_old.c - x0.c;
+        if (dotd(dxx, dxx) < eps_x) break;
+        grad = prob.gradient(x0);
+        double gradNorm = absmax(grad);
+        if (gradNorm < eps_g) { new_hess_guess = gamma_k; break; }
+        V3 s_temp, y_temp;
+        s_temp.a = x0.a - x_old.a; s_temp.b = x0.b - x_old.b; s_temp.c = x0.c - x_old.c;
+        y_temp.a = grad.a - grad_old.a; y_temp.b = grad.b - grad_old.b; y_temp.c = grad.c - grad_old.c;
+        if (k < m_) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) if (i == k) { s[i] = s_temp; y[i] = y_temp; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M - 1; ++i) if (i < m_ - 1) { s[i] = s[i + 1]; y[i] = y[i + 1]; }
+#pragma unroll
+            for (int i = 0; i < M; ++i) if (i == m_ - 1) { s[i] = s_temp; y[i] = y_temp; }
+        }
+        gamma_k = dotd(s_temp, y_temp) / dotd(y_temp, y_temp);
+        alpha_init = 1.0;
+    }
+    init_hess = new_hess_guess;
+    return globIter;
+}
+
+// ---- HyperElasticTet::project on F = Dx_i + u_i, CORE/TetForce.cpp:320-364 ----
+// state: sa,sb,sc = last_prox_result, hess = solver->settings_.init_hess.
+// Returns z (= U diag(sigma) V^T) and the L-BFGS iteration count.
+template <int TYPE, int M>
+ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter, double &sa, double &sb, double &sc, double &hess, int &n_iters) {
+    double s0, s1, s2; Mat3 U, V;
+    oriented_svd(F, s0, s1, s2, U, V);
+    Prox<TYPE> P;
+    P.mu = mu; P.lambda = lambda; P.k = smin(mu, lambda);
+    P.s0.a = s0; P.s0.b = s1; P.s0.c = s2;
+    V3 x2; x2.a = sa; x2.b = sb; x2.c = sc;
+    if (x2.c < 0.0) x2.c *= -1.0;
+    else if (fabs(x2.a) < 1.e-3 && fabs(x2.b) < 1.e-3 && fabs(x2.c) < 1.e-3) { x2.a = 1.e-3; x2.b = 1.e-3; x2.c = 1.e-3; }
+    n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
+    sa = x2.a; sb = x2.b; sc = x2.c;
+    return recompose(U, x2.a, x2.b, x2.c, V);
+}
+
+// ---- LinearTetStrain::project (CORE/TetForce.cpp:127-153) and TetVolume::project (:173-210)
+// d = Dx_i + u_i ; returns the projection p (before the weighted blend)
+template <bool VOLUME> ADMM_HD Mat3 project_tet_p(const Mat3 &d, double limit_min, double limit_max) {
+    double s0, s1, s2; Mat3 U, V;
+    svd3(d, U, s0, s1, s2, V);
+    double n0, n1, n2;
+    if (!VOLUME) { n0 = 1.0; n1 = 1.0; n2 = 1.0; }
+    else {
+        double d0 = 0, d1 = 0, d2 = 0;
+        n0 = s0; n1 = s1; n2 = s2;
+        for (int it = 0; it < 4; ++it) {
+            double detS = n0 * n1 * n2;
+            double f = detS - smin(smax(detS, limit_min), limit_max);
+            double g0 = n1 * n2, g1 = n0 * n2, g2 = n0 * n1;
+            double gd = g0 * d0 + (g1 * d1 + g2 * d2);
+            double gg = g0 * g0 + (g1 * g1 + g2 * g2);
+            double sc = -((f - gd) / gg);
+            d0 = sc * g0; d1 = sc * g1; d2 = sc * g2;
+            n0 = s0 + d0; n1 = s1 + d1; n2 = s2 + d2;
+        }
+    }
+    if (det3(d) < 0.0) n2 = -1.0;
+    return recompose(U, n0, n1, n2, V);
+}
+
+} // namespace admm_dev

@@ -1,0 +1,171 @@
+/*
+ * admm_hip.h -- C ABI of the MI355X-native ADMM elastic solver (libadmm_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of mattoverby/admm-elastic-sca:
+ * everything admm::System::initialize()/step() does between "forces and nodes
+ * are known" and "m_x/m_v hold the new state" (reference
+ * deps/admm-elastic-sca/src/system/System.cpp:26-75 and :98-179) runs behind
+ * these entry points, on one GPU per context.  The reference itself has no
+ * FFI: its plugin surface is the C++ classes admm::System / admm::Force.  The
+ * host-side mirror of those classes (admm-elastic-sca_amd/host/admm/*.hpp)
+ * binds to exactly the functions declared here, and so does the Python
+ * plumbing used by bench.py and tests/.  Plain C types only, caller-owned
+ * host buffers, int error codes (0 = ok), no exceptions across the boundary.
+ *
+ * Every entry point cites the reference interface it replaces.
+ */
+#ifndef ADMM_HIP_H
+#define ADMM_HIP_H
+
+#include <stdint.h>
+#include "admm_kinds.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct admm_hip_ctx admm_hip_ctx;
+
+enum admm_hip_err {
+    ADMM_OK = 0,
+    ADMM_ERR_ARG = 1,        /* bad argument / call order                       */
+    ADMM_ERR_HIP = 2,        /* a HIP runtime call failed (no GPU, OOM, ...)    */
+    ADMM_ERR_STATE = 3,      /* not finalized / already finalized               */
+    ADMM_ERR_UNSUPPORTED = 4,/* input outside the accelerated path              */
+    ADMM_ERR_FACTOR = 5,     /* matrix not positive definite                    */
+    ADMM_ERR_COMM = 6        /* all-reduce hook failed                          */
+};
+
+/* ---- lifetime -------------------------------------------------------------
+ * replaces: admm::System::System() / ~System()            (System.hpp:31)
+ * device_id < 0: host-only context (assembly + factorization work, every
+ * device call returns ADMM_ERR_HIP) -- used by the CPU test-suite.          */
+int  admm_hip_create(admm_hip_ctx **out, int device_id);
+void admm_hip_destroy(admm_hip_ctx *ctx);
+const char *admm_hip_last_error(const admm_hip_ctx *ctx);
+/* run on an existing hipStream_t (e.g. torch's current stream); NULL = own stream */
+int  admm_hip_set_stream(admm_hip_ctx *ctx, void *hip_stream);
+
+/* ---- settings -------------------------------------------------------------
+ * replaces: System::settings.timestep_s / admm_iters      (System.hpp:36-44)
+ * dt <= 0 is repaired to 0.04 like System::initialize     (System.cpp:103-107) */
+int admm_hip_set_timestep(admm_hip_ctx *ctx, double dt);
+
+/* ---- nodes ----------------------------------------------------------------
+ * replaces: System::add_nodes(x, m)                       (System.cpp:78-95)
+ * x, m: [3*n_nodes] xyz-interleaved like m_x / m_masses; velocities start at 0.
+ * May be called several times before finalize; returns total node count in *total. */
+int admm_hip_add_nodes(admm_hip_ctx *ctx, int n_nodes, const double *x, const double *m, int *total);
+
+/* ---- forces ---------------------------------------------------------------
+ * replaces: system->forces.push_back(new <Force>(...)) for n_elems elements of
+ * one kind, in order                                      (System.hpp:52;
+ * constructors: Force.hpp:65, TetForce.hpp:33,54,118, TriangleForce.hpp:32,
+ * BendForce.hpp:31, AnchorForce.hpp:57,88).
+ * idx    : [n_elems][ADMM_KIND_NODES[kind]] node ids
+ * params : [n_elems][ADMM_KIND_PARAMS[kind]]  (layout in admm_kinds.h)
+ * targets: ANCHOR only, [n_elems][3] control-point positions for MovingAnchor
+ *          semantics, or NULL for StaticAnchor (target = x at finalize).
+ * The order of add_batch calls and of elements inside a batch is the order of
+ * system->forces; it defines global_idx exactly as Force::get_selector does.
+ * Returns the batch id in *batch. */
+int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *idx,
+                       const double *params, const double *targets, int *batch);
+
+/* replaces: system->explicit_forces.push_back(new ExplicitForce(dir))
+ * (ExplicitForce.hpp:51-59, ExplicitForce.cpp:29-39): v += dt*dir on all nodes,
+ * once per frame before the ADMM loop.                                       */
+int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz);
+
+/* ---- multi-GPU ------------------------------------------------------------
+ * Elements shard across ranks (contiguous element ranges per batch); nodes and
+ * the factor are replicated.  Must be called before finalize.  The hook is
+ * invoked once per ADMM iteration between RHS assembly and the solve with the
+ * device pointer of the partial RHS (count doubles, on `stream`): it must
+ * sum it in place across ranks (RCCL all-reduce).  No reference counterpart
+ * (the reference is single-process).                   */
+typedef int (*admm_hip_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *hip_stream);
+int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world);
+int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user);
+
+/* ---- initialize -----------------------------------------------------------
+ * replaces: System::initialize()                          (System.cpp:98-156)
+ * Force::initialize + get_selector for every element (rest shape matrices,
+ * weights, global_idx), assembly of A = M + dt^2 D^T W^2 D, its sparse
+ * factorization (host) and the upload of every device-resident array.        */
+int admm_hip_finalize(admm_hip_ctx *ctx);
+
+/* replaces: System::recompute_weights()                   (System.cpp:159-179)
+ * after admm_hip_set_weights changed per-element weights: re-assemble, re-factor, re-upload. */
+int admm_hip_set_weights(admm_hip_ctx *ctx, int batch, const double *weights);
+int admm_hip_recompute_weights(admm_hip_ctx *ctx);
+
+/* ---- per-frame host-mutable parameters --------------------------------------
+ * replaces: writes to ControlPoint::pos / ::active from callbacks
+ * (AnchorForce.hpp:71-80; samples/poordillo/poordillo.cpp:196-248)           */
+int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets, const int32_t *active);
+/* replaces: writes to ExplicitForce::direction (samples/windyflag/windyflag.cpp:141-152) */
+int admm_hip_set_gravity(admm_hip_ctx *ctx, int which, double gx, double gy, double gz);
+
+/* ---- step -----------------------------------------------------------------
+ * replaces: System::step()                                (System.cpp:26-75)
+ * one frame: explicit forces, x_bar, admm_iters x (local step, RHS, solve),
+ * velocity update.  Asynchronous on the context's stream; admm_hip_sync or any
+ * get_* call waits for it.  pre_step_callbacks stay on the host side
+ * (host/admm/System.hpp runs them before calling this).                      */
+int admm_hip_step(admm_hip_ctx *ctx, int admm_iters);
+int admm_hip_sync(admm_hip_ctx *ctx);
+
+/* ---- state access ---------------------------------------------------------
+ * replaces: reads/writes of System::m_x, m_v              (System.hpp:47-49) */
+int admm_hip_get_x(admm_hip_ctx *ctx, double *x);
+int admm_hip_set_x(admm_hip_ctx *ctx, const double *x);
+int admm_hip_get_v(admm_hip_ctx *ctx, double *v);
+int admm_hip_set_v(admm_hip_ctx *ctx, const double *v);
+
+/* ---- parity / introspection ------------------------------------------------
+ * u, z: [n_local_elems][rows] element-major (compact rows), state:
+ * [n_local_elems][ADMM_KIND_STATE]; n_iters: L-BFGS outer iterations of the last
+ * project (hyperelastic kinds).  Any pointer may be NULL.  Replaces the
+ * protected System::curr_u / curr_z (System.hpp:98-99) and
+ * HyperElasticTet::last_prox_result (TetForce.hpp:146).                      */
+int admm_hip_read_local(admm_hip_ctx *ctx, int batch, double *u, double *z, double *state, int32_t *n_iters);
+int admm_hip_write_local(admm_hip_ctx *ctx, int batch, const double *u, const double *state);
+/* rest data computed by Force::initialize: weight [n], rest [n][12] (tets: B 4x3
+ * col-major; tris: B 3x2 in the first 6; bend: alpha[4]; spring: rest length),
+ * global_idx [n] (compact row of the element's first row).                    */
+int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *rest, int32_t *global_idx);
+
+/* one local step on caller-supplied positions (no global step): runs the batch
+ * kernels on x_cur = x and returns; used by the per-project parity tests.     */
+int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur);
+/* solves A X = B for B = [n_nodes][3] on the device factor (parity tests).    */
+int admm_hip_solve_only(admm_hip_ctx *ctx, const double *b, double *x);
+/* host-side product with the assembled scalar matrix: y = A_s * x, x,y [n][3] */
+int admm_hip_apply_A(admm_hip_ctx *ctx, const double *x, double *y);
+
+typedef struct admm_hip_info {
+    int64_t n_nodes, n_elems_total, n_elems_local, rows_compact;
+    int64_t nnz_A;            /* scalar n x n system, lower triangle          */
+    int64_t nnz_L;            /* entries of the supernodal factor panels read per triangular sweep */
+    int64_t panel_bytes;      /* device bytes of the factor panels            */
+    int64_t n_supernodes, n_levels, max_super_cols, max_super_rows;
+    int64_t solve_contrib_rows; /* sum of below-diagonal block rows            */
+    double  t_order_s, t_symbolic_s, t_numeric_s, t_upload_s; /* finalize phases */
+    int32_t rank, world, device_id, host_threads;
+} admm_hip_info;
+int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
+
+/* per-phase device timing of the last admm_hip_step (HIP events on the
+ * context's stream; enabled with admm_hip_enable_timing).  ms per frame.      */
+typedef struct admm_hip_timing {
+    float prologue_ms, local_ms, rhs_ms, allreduce_ms, solve_fwd_ms, solve_bwd_ms, epilogue_ms, total_ms;
+    int32_t iters;
+} admm_hip_timing;
+int admm_hip_enable_timing(admm_hip_ctx *ctx, int on);
+int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
