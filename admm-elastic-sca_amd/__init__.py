@@ -95,6 +95,7 @@ def lib():
         L.admm_hip_write_local.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.admm_hip_read_rest.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
         L.admm_hip_solve_only.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_local_step_dx.argtypes = [C.c_void_p, C.c_int, _dp]
         L.admm_hip_apply_A.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_panel_solve_host.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
@@ -271,6 +272,10 @@ class System:
     def local_step_only(self, x_cur):
         x_cur = np.ascontiguousarray(x_cur, dtype=np.float64).ravel()
         self._chk(self.L.admm_hip_local_step_only(self.h, _d(x_cur)))
+
+    def local_step_dx(self, batch, dx):
+        dx = np.ascontiguousarray(dx, dtype=np.float64)
+        self._chk(self.L.admm_hip_local_step_dx(self.h, batch, _d(dx)))
 
     def solve_only(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64).ravel()

@@ -45,6 +45,7 @@ struct Batch {
     int *d_idx = nullptr, *d_active = nullptr, *d_niters = nullptr;
     double *d_rest = nullptr, *d_par = nullptr, *d_w2h2 = nullptr, *d_kblend = nullptr, *d_w2 = nullptr;
     double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
+    double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
 };
 
 struct LevelDev {
@@ -84,7 +85,8 @@ struct admm_hip_ctx {
     std::vector<void *> allocs;
     // timing
     bool timing = false;
-    hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
+    size_t ev_used = 0; int ev_iters = 0; bool ev_pending = false;
     admm_hip_timing last_timing{};
 };
 
@@ -328,7 +330,6 @@ int upload_all(admm_hip_ctx *ctx) {
         for (int i = 0; i < n; ++i) { ptr[i + 1] = ptr[i] + (int64_t)inc[i].size(); sl.insert(sl.end(), inc[i].begin(), inc[i].end()); }
         TRY(upload(ctx, &ctx->d_inc_ptr, ptr)); TRY(upload(ctx, &ctx->d_inc_slot, sl));
     }
-    if (ctx->timing) for (int i = 0; i < 8; ++i) if (!ctx->ev[i]) HIPCHK(hipEventCreate(&ctx->ev[i]));
     HIPCHK(hipDeviceSynchronize());
     ctx->info.t_upload_s = now_s() - t0;
     return ADMM_OK;
@@ -339,6 +340,7 @@ BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     d.n = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
     d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
     d.fslot = ctx->d_fslot + 3 * (size_t)b.slot_base; d.targets = b.d_targets; d.active = b.d_active;
+    d.dx_override = b.d_dx_override;
     return d;
 }
 
@@ -353,9 +355,11 @@ FactorDev factor_dev(const admm_hip_ctx *ctx) {
 int max_lbfgs_iters(const Batch &b) { return b.max_iter; }
 
 // local step: every batch kernel on x_cur
-int launch_local(admm_hip_ctx *ctx) {
+int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
     using namespace admm_dev;
-    for (const Batch &b : ctx->batches) {
+    for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
+        const Batch &b = ctx->batches[bi];
+        if (only_batch >= 0 && (int)bi != only_batch) continue;
         if (b.n_local == 0) continue;
         const BatchDev d = batch_dev(ctx, b);
         const dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
@@ -453,7 +457,7 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         (void)hipSetDevice(ctx->device_id);
         (void)hipDeviceSynchronize();
         free_device(ctx);
-        for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+        for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -590,53 +594,45 @@ int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets,
     return ADMM_OK;
 }
 
+// records the next pooled event on the stream (timing mode only)
+static int mark(admm_hip_ctx *ctx) {
+    if (!ctx->timing) return ADMM_OK;
+    if (ctx->ev_used == ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
+    HIPCHK(hipEventRecord(ctx->evpool[ctx->ev_used++], ctx->stream));
+    return ADMM_OK;
+}
+
 int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     TRY(require_device(ctx));
     using namespace admm_dev;
     HIPCHK(hipSetDevice(ctx->device_id));
     const int n3 = 3 * ctx->n_nodes;
-    const bool tm = ctx->timing;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    // event layout (timing mode): E0 | prologue | E1 | per iter: local E rhs E allreduce E fwd E bwd E | epilogue | E
+    ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_pending = ctx->timing;
+    TRY(mark(ctx));
     hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
-    if (tm) { HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream)); }
+    TRY(mark(ctx));
     for (int it = 0; it < admm_iters; ++it) {
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
         TRY(launch_local(ctx));
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+        TRY(mark(ctx));
         TRY(launch_rhs(ctx));
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+        TRY(mark(ctx));
         if (ctx->world > 1) {
             if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
             if (ctx->allreduce(ctx->allreduce_user, ctx->d_y, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
         }
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
-        TRY(launch_solve(ctx, tm ? ctx->ev[6] : nullptr));
-        if (tm) {
-            HIPCHK(hipEventRecord(ctx->ev[7], ctx->stream));
-            HIPCHK(hipEventSynchronize(ctx->ev[7]));
-            float t;
-            HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3])); acc[1] += t;
-            HIPCHK(hipEventElapsedTime(&t, ctx->ev[3], ctx->ev[4])); acc[2] += t;
-            HIPCHK(hipEventElapsedTime(&t, ctx->ev[4], ctx->ev[5])); acc[3] += t;
-            HIPCHK(hipEventElapsedTime(&t, ctx->ev[5], ctx->ev[6])); acc[4] += t;
-            HIPCHK(hipEventElapsedTime(&t, ctx->ev[6], ctx->ev[7])); acc[5] += t;
+        TRY(mark(ctx));
+        hipEvent_t mid = nullptr;
+        if (ctx->timing) {
+            if (ctx->ev_used == ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
+            mid = ctx->evpool[ctx->ev_used++];
         }
+        TRY(launch_solve(ctx, mid));
+        TRY(mark(ctx));
     }
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
     HIPCHK(hipGetLastError());
-    if (tm) {
-        HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-        HIPCHK(hipEventSynchronize(ctx->ev[3]));
-        float t;
-        HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1])); acc[0] = t;
-        HIPCHK(hipEventElapsedTime(&t, ctx->ev[2], ctx->ev[3])); acc[6] = t;
-        HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3])); acc[7] = t;
-        admm_hip_timing &T = ctx->last_timing;
-        T.prologue_ms = acc[0]; T.local_ms = acc[1]; T.rhs_ms = acc[2]; T.allreduce_ms = acc[3]; T.solve_fwd_ms = acc[4]; T.solve_bwd_ms = acc[5];
-        T.epilogue_ms = acc[6]; T.total_ms = acc[7]; T.iters = admm_iters;
-    }
+    TRY(mark(ctx));
     return ADMM_OK;
 }
 
@@ -752,6 +748,29 @@ int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur) {
     return ADMM_OK;
 }
 
+// Parity-test hook: one project() of every local element of `batch` on
+// caller-supplied D_i x rows (element-major [n_local][rows]) instead of the
+// gather from x -- replays the reference's recorded (Dx,u,state)->(u,z,state) tuples.
+int admm_hip_local_step_dx(admm_hip_ctx *ctx, int batch, const double *dx) {
+    TRY(require_device(ctx));
+    if (batch < 0 || batch >= (int)ctx->batches.size() || !dx) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    Batch &b = ctx->batches[batch];
+    const int rows = ADMM_KIND_ROWS[b.kind], n = b.n_local;
+    if (n == 0) return ADMM_OK;
+    std::vector<double> tmp((size_t)rows * n);
+    for (int e = 0; e < n; ++e) for (int r = 0; r < rows; ++r) tmp[(size_t)r * n + e] = dx[(size_t)e * rows + r];
+    if (!b.d_dx_buf) TRY(dalloc(ctx, &b.d_dx_buf, tmp.size()));
+    HIPCHK(hipMemcpy(b.d_dx_buf, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    b.d_dx_override = b.d_dx_buf;
+    int rc = launch_local(ctx, batch);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    b.d_dx_override = nullptr;             // production launches never see the override
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, ADMM_ERR_HIP, "local_step_dx: %s", hipGetErrorString(e));
+    return ADMM_OK;
+}
+
 int admm_hip_solve_only(admm_hip_ctx *ctx, const double *b, double *x) {
     TRY(require_device(ctx));
     if (!b || !x) return ADMM_ERR_ARG;
@@ -783,11 +802,34 @@ int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info) {
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->timing = on != 0;
-    if (ctx->timing && ctx->device_id >= 0) { HIPCHK(hipSetDevice(ctx->device_id)); for (int i = 0; i < 8; ++i) if (!ctx->ev[i]) HIPCHK(hipEventCreate(&ctx->ev[i])); }
     return ADMM_OK;
 }
+// Reads back the events of the last step recorded in timing mode (waits for it).
 int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t) {
     if (!ctx || !t) return ADMM_ERR_ARG;
+    if (ctx->ev_pending && ctx->device_id >= 0) {
+        HIPCHK(hipSetDevice(ctx->device_id));
+        const std::vector<hipEvent_t> &E = ctx->evpool;
+        const size_t need = 3 + 5 * (size_t)ctx->ev_iters;
+        if (ctx->ev_used != need) return fail(ctx, ADMM_ERR_STATE, "timing events incomplete (%zu of %zu)", ctx->ev_used, need);
+        HIPCHK(hipEventSynchronize(E[need - 1]));
+        admm_hip_timing T{};
+        float v;
+        HIPCHK(hipEventElapsedTime(&v, E[0], E[1])); T.prologue_ms = v;
+        for (int it = 0; it < ctx->ev_iters; ++it) {
+            const size_t b = 1 + 5 * (size_t)it;
+            HIPCHK(hipEventElapsedTime(&v, E[b], E[b + 1])); T.local_ms += v;
+            HIPCHK(hipEventElapsedTime(&v, E[b + 1], E[b + 2])); T.rhs_ms += v;
+            HIPCHK(hipEventElapsedTime(&v, E[b + 2], E[b + 3])); T.allreduce_ms += v;
+            HIPCHK(hipEventElapsedTime(&v, E[b + 3], E[b + 4])); T.solve_fwd_ms += v;
+            HIPCHK(hipEventElapsedTime(&v, E[b + 4], E[b + 5])); T.solve_bwd_ms += v;
+        }
+        HIPCHK(hipEventElapsedTime(&v, E[need - 2], E[need - 1])); T.epilogue_ms = v;
+        HIPCHK(hipEventElapsedTime(&v, E[0], E[need - 1])); T.total_ms = v;
+        T.iters = ctx->ev_iters;
+        ctx->last_timing = T;
+        ctx->ev_pending = false;
+    }
     *t = ctx->last_timing;
     return ADMM_OK;
 }

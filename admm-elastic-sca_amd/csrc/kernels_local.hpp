@@ -46,6 +46,7 @@ struct BatchDev {
     double *fslot;         // [n*nodes][3]
     double *targets;       // anchors: [n][3]
     const int *active;     // anchors: [n]
+    const double *dx_override; // parity tests: SoA [rows][n] of D_i x to use instead of the gather (NULL in production)
 };
 
 ADMM_HD Mat3 mat_add(const Mat3 &a, const Mat3 &b) {
@@ -102,6 +103,12 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tet_kernel(BatchDev b, co
         Dx.m01 = ADMM_DX(1, p0x, p1x, p2x, p3x); Dx.m11 = ADMM_DX(1, p0y, p1y, p2y, p3y); Dx.m21 = ADMM_DX(1, p0z, p1z, p2z, p3z);
         Dx.m02 = ADMM_DX(2, p0x, p1x, p2x, p3x); Dx.m12 = ADMM_DX(2, p0y, p1y, p2y, p3y); Dx.m22 = ADMM_DX(2, p0z, p1z, p2z, p3z);
 #undef ADMM_DX
+        if (b.dx_override) {
+            const double *o = b.dx_override;
+            Dx.m00 = o[(size_t)0 * n + ec]; Dx.m10 = o[(size_t)1 * n + ec]; Dx.m20 = o[(size_t)2 * n + ec];
+            Dx.m01 = o[(size_t)3 * n + ec]; Dx.m11 = o[(size_t)4 * n + ec]; Dx.m21 = o[(size_t)5 * n + ec];
+            Dx.m02 = o[(size_t)6 * n + ec]; Dx.m12 = o[(size_t)7 * n + ec]; Dx.m22 = o[(size_t)8 * n + ec];
+        }
         Mat3 u;
         u.m00 = b.u[(size_t)0 * n + ec]; u.m10 = b.u[(size_t)1 * n + ec]; u.m20 = b.u[(size_t)2 * n + ec];
         u.m01 = b.u[(size_t)3 * n + ec]; u.m11 = b.u[(size_t)4 * n + ec]; u.m21 = b.u[(size_t)5 * n + ec];
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b,
     const bool act = b.active[e] != 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
+        double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
+        if (b.dx_override) dx = b.dx_override[(size_t)j * n + e];
         const double u = b.u[(size_t)j * n + e];
         double zi;
         if (act) zi = b.targets[3 * (size_t)e + j];
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b,
         const double xa = x[3 * (size_t)ia + j], xb = x[3 * (size_t)ib + j];
         // column-ascending accumulation of (+1) x_a + (-1) x_b
         dx[j] = (ia < ib) ? ((0.0 + 1.0 * xa) + -1.0 * xb) : ((0.0 + -1.0 * xb) + 1.0 * xa);
+        if (b.dx_override) dx[j] = b.dx_override[(size_t)j * n + e];
         u[j] = b.u[(size_t)j * n + e];
         d[j] = dx[j] + u[j];
     }
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, c
         for (int r = 0; r < 3; ++r) {
             const double xp = x[3 * (size_t)plus[r] + j];
             dx[r] = (plus[r] < id.z) ? ((0.0 + 1.0 * xp) + -1.0 * x2) : ((0.0 + -1.0 * x2) + 1.0 * xp);
+            if (b.dx_override) dx[r] = b.dx_override[(size_t)(3 * r + j) * n + e];
             u[r] = b.u[(size_t)(3 * r + j) * n + e];
             d[r] = dx[r] + u[r];
         }
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             dx[3 * r + j] = ((0.0 + B[0 + 3 * r] * xa) + B[1 + 3 * r] * xb) + B[2 + 3 * r] * xc;
+            if (b.dx_override) dx[3 * r + j] = b.dx_override[(size_t)(3 * r + j) * n + e];
             u[3 * r + j] = b.u[(size_t)(3 * r + j) * n + e];
             d[3 * r + j] = dx[3 * r + j] + u[3 * r + j];
         }

@@ -139,10 +139,17 @@ int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *res
 /* one local step on caller-supplied positions (no global step): runs the batch
  * kernels on x_cur = x and returns; used by the per-project parity tests.     */
 int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur);
+/* one project() of every local element of `batch` on caller-supplied D_i x rows
+ * (element-major [n_local][rows]) instead of the gather: replays the per-project
+ * golden tuples captured from the reference (tests/golden/project_*.npz).       */
+int admm_hip_local_step_dx(admm_hip_ctx *ctx, int batch, const double *dx);
 /* solves A X = B for B = [n_nodes][3] on the device factor (parity tests).    */
 int admm_hip_solve_only(admm_hip_ctx *ctx, const double *b, double *x);
 /* host-side product with the assembled scalar matrix: y = A_s * x, x,y [n][3] */
 int admm_hip_apply_A(admm_hip_ctx *ctx, const double *x, double *y);
+/* CPU evaluation of the factor's two panel sweeps -- validation hook for the
+ * CPU test-suite only; no product path calls it.                               */
+int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *x);
 
 typedef struct admm_hip_info {
     int64_t n_nodes, n_elems_total, n_elems_local, rows_compact;

@@ -1,0 +1,82 @@
+"""CPU: the product's per-element device math (csrc/local_math.hpp), compiled
+for the host by tests/host_math_shim.cpp, against the oracle: bit-exact --
+the very same header is what the HIP kernels execute per lane."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from checkers import KIND, Oracle, dp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hm():
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    out = os.path.join(HERE, "_build", "libhostmath.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, os.path.join(HERE, "host_math_shim.cpp")])
+    lib = C.CDLL(out)
+    lib.hm_project_hyper.argtypes = [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_int, dp, dp]
+    lib.hm_project_tet_p.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def test_svd3(hm):
+    rng = np.random.default_rng(3)
+    for t in range(3000):
+        F = rng.normal(size=9) * 10 ** rng.uniform(-3, 3)
+        if t % 5 == 0:
+            F = (np.eye(3) + 0.3 * rng.normal(size=(3, 3))).ravel()
+        if t % 17 == 0:
+            F[3:6] = F[0:3]
+        if t % 501 == 0:
+            F[:] = 0
+        a = Oracle.svd3(F)
+        U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+        hm.hm_svd3(_p(F), _p(U), _p(S), _p(V))
+        assert np.array_equal(a[0], U) and np.array_equal(a[1], S) and np.array_equal(a[2], V)
+
+
+@pytest.mark.parametrize("name,params,M", [("TET_NH", [1e5, 1e5, 5], 5), ("TET_NH", [50, 80, 20], 10), ("TET_NH", [1e3, 2e3, 3], 5),
+                                           ("TET_STVK", [100, 100, 5], 5), ("TET_STVK", [3e3, 1e3, 12], 10), ("TET_STVK", [1e5, 1e5, 1], 5)])
+def test_project_hyper(hm, name, params, M):
+    kind = KIND[name]
+    rng = np.random.default_rng(11)
+    x_rest = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.]])
+    for t in range(400):
+        amp = rng.choice([0.0, 1e-8, 0.01, 0.1, 0.3, 0.6])
+        Dx = []
+        for c in range(5):
+            A = np.eye(3) + amp * rng.normal(size=(3, 3))
+            if rng.uniform() < 0.1:
+                A[:, 2] *= -1
+            Dx.append(A.ravel(order="F"))
+        Dx = np.array(Dx); u0 = rng.normal(size=9) * rng.choice([0, 0.01, 0.1])
+        b = Oracle.project_single(kind, x_rest, params, Dx, u0)
+        st = np.array([1., 1, 1, 1]); u = u0.copy()
+        for c in range(5):
+            Fm = np.ascontiguousarray(Dx[c] + u); z = np.zeros(9)
+            it = hm.hm_project_hyper(kind - 4, M, _p(Fm), params[0], params[1], int(params[2]), _p(st), _p(z))
+            u = u + (Dx[c] - z)
+            assert np.array_equal(z, b["z"][c], equal_nan=True) and it == b["n_iters"][c] and np.array_equal(u, b["u"][c], equal_nan=True)
+        assert np.array_equal(st, b["state"], equal_nan=True)
+
+
+def test_project_tet_blend(hm):
+    rng = np.random.default_rng(5)
+    x_rest = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.]])
+    for vol in (0, 1):
+        for t in range(1000):
+            d = (np.eye(3) + rng.choice([0.01, 0.3, 1.0]) * rng.normal(size=(3, 3))).ravel()
+            p = np.zeros(9)
+            hm.hm_project_tet_p(vol, _p(d), 0.9, 1.1, _p(p))
+            b = Oracle.project_single(3 if vol else 2, x_rest, [100, 0.9, 1.1] if vol else [100.], d.reshape(1, 9), np.zeros(9))
+            w = b["init"][0]; k = 100 * b["init"][13]; w2 = w * w
+            assert np.array_equal((k * p + w2 * d) / (w2 + k), b["z"][0])
