@@ -42,14 +42,13 @@ struct Batch {
     int64_t slot_base = 0;                       // first local force slot
     int max_iter = 0;                            // largest L-BFGS max_iterations (hyperelastic kinds)
     // device
-    int *d_idx = nullptr, *d_active = nullptr, *d_niters = nullptr;
+    int *d_idx = nullptr, *d_dst = nullptr, *d_active = nullptr, *d_niters = nullptr;
     double *d_rest = nullptr, *d_par = nullptr, *d_w2h2 = nullptr, *d_kblend = nullptr, *d_w2 = nullptr;
     double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
 };
 
 struct LevelDev {
-    int n_cols = 0; int *d_cols = nullptr;                       // gather
     int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
     int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
     int n_bwd = 0; int *d_bwd_sn = nullptr, *d_bwd_chunk = nullptr;
@@ -78,9 +77,9 @@ struct admm_hip_ctx {
     // device state (node arrays in factor order)
     double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
     double *d_fslot = nullptr; int64_t n_fslots = 0;
-    int64_t *d_inc_ptr = nullptr; int *d_inc_slot = nullptr;
-    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_gat_slot = nullptr;
-    int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_gat_ptr = nullptr;
+    int64_t *d_inc_ptr = nullptr;
+    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr;
+    int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
     // timing
@@ -221,29 +220,28 @@ int upload_factor(admm_hip_ctx *ctx) {
     Factor &F = ctx->F;
     const int ns = (int)F.sn.size();
     std::vector<int> first(ns), ncols(ns), nrows(ns);
-    std::vector<int64_t> poff(ns), roff(ns), soff(ns);
-    for (int s = 0; s < ns; ++s) { first[s] = F.sn[s].first; ncols[s] = F.sn[s].ncols; nrows[s] = F.sn[s].nrows; poff[s] = F.sn[s].panel_off; roff[s] = F.sn[s].rows_off; soff[s] = F.sn[s].slot_off; }
+    std::vector<int64_t> poff(ns), roff(ns), soff(ns), foff(ns);
+    for (int s = 0; s < ns; ++s) { first[s] = F.sn[s].first; ncols[s] = F.sn[s].ncols; nrows[s] = F.sn[s].nrows; poff[s] = F.sn[s].panel_off; roff[s] = F.sn[s].rows_off; soff[s] = F.sn[s].slot_off; foff[s] = F.sn[s].front_off; }
     TRY(upload(ctx, &ctx->d_panels, F.panels));
     TRY(upload(ctx, &ctx->d_sn_first, first)); TRY(upload(ctx, &ctx->d_sn_ncols, ncols)); TRY(upload(ctx, &ctx->d_sn_nrows, nrows));
     TRY(upload(ctx, &ctx->d_sn_panel_off, poff)); TRY(upload(ctx, &ctx->d_sn_rows_off, roff)); TRY(upload(ctx, &ctx->d_sn_slot_off, soff));
     TRY(upload(ctx, &ctx->d_rows, F.rows));
-    TRY(upload(ctx, &ctx->d_gat_ptr, F.gat_ptr)); TRY(upload(ctx, &ctx->d_gat_slot, F.gat_slot));
+    TRY(upload(ctx, &ctx->d_sn_front_off, foff));
+    TRY(upload(ctx, &ctx->d_cg_ptr, F.cg_ptr)); TRY(upload(ctx, &ctx->d_cg_slot, F.cg_slot));
     TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
     ctx->levels.assign(F.levels.size(), LevelDev());
     for (size_t l = 0; l < F.levels.size(); ++l) {
         LevelDev &L = ctx->levels[l];
-        std::vector<int> cols, ssn, stile, bsn, btile, wsn, wchunk;
+        std::vector<int> ssn, stile, bsn, btile, wsn, wchunk;
         for (int s : F.levels[l]) {
             const Supernode &S = F.sn[s];
             const int f = S.ncols + S.nrows;
-            if (F.gat_ptr[S.first + S.ncols] > F.gat_ptr[S.first]) for (int j = 0; j < S.ncols; ++j) cols.push_back(S.first + j);
             const int tiles = (f + 63) / 64;
             for (int t = 0; t < tiles; ++t) { if (S.ncols <= admm_dev::FWD_SMALL_KMAX) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
             const int chunks = (S.ncols + admm_dev::BWD_COLS - 1) / admm_dev::BWD_COLS;
             for (int c = 0; c < chunks; ++c) { wsn.push_back(s); wchunk.push_back(c); }
         }
-        L.n_cols = (int)cols.size(); L.n_small = (int)ssn.size(); L.n_big = (int)bsn.size(); L.n_bwd = (int)wsn.size();
-        TRY(upload(ctx, &L.d_cols, cols));
+        L.n_small = (int)ssn.size(); L.n_big = (int)bsn.size(); L.n_bwd = (int)wsn.size();
         TRY(upload(ctx, &L.d_small_sn, ssn)); TRY(upload(ctx, &L.d_small_tile, stile));
         TRY(upload(ctx, &L.d_big_sn, bsn)); TRY(upload(ctx, &L.d_big_tile, btile));
         TRY(upload(ctx, &L.d_bwd_sn, wsn)); TRY(upload(ctx, &L.d_bwd_chunk, wchunk));
@@ -266,31 +264,44 @@ int upload_all(admm_hip_ctx *ctx) {
     TRY(upload_factor(ctx));
     // batches: shard, sort corners, SoA upload
     int64_t slot = 0, nloc = 0;
-    std::vector<std::vector<int>> inc(n); // per permuted node: slots
+    // pass 1: local ranges, corner order, incidence counts per (factor-order) node
+    std::vector<int64_t> inc_ptr(n + 1, 0);
     for (Batch &b : ctx->batches) {
-        const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
+        const int nn = ADMM_KIND_NODES[b.kind];
         b.first = (int)((int64_t)b.n_total * ctx->rank / ctx->world);
         const int end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
         b.n_local = end - b.first;
-        const int nl = b.n_local;
         b.slot_base = slot;
         const bool sort_corners = (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TRI_STRAIN);
         b.max_iter = 0;
         if (b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK)
             for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
-        std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0);
-        std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
         b.corner_perm.assign((size_t)b.n_total * nn, 0);
-        for (int el = 0; el < nl; ++el) {
+        for (int el = 0; el < b.n_local; ++el) {
             const int e = b.first + el;
             const int *id = b.idx.data() + (size_t)e * nn;
             int ord[4] = {0, 1, 2, 3};
             if (sort_corners) std::stable_sort(ord, ord + nn, [&](int a, int c) { return id[a] < id[c]; });
+            for (int c = 0; c < nn; ++c) { b.corner_perm[(size_t)e * nn + c] = ord[c]; inc_ptr[F.iperm[id[ord[c]]] + 1]++; }
+        }
+        slot += (int64_t)b.n_local * nn; nloc += b.n_local;
+    }
+    for (int i = 0; i < n; ++i) inc_ptr[i + 1] += inc_ptr[i];
+    std::vector<int64_t> inc_pos(inc_ptr.begin(), inc_ptr.end() - 1);
+    // pass 2: device arrays; every corner gets the next slot of its node (fixed order: batch, element, corner)
+    for (Batch &b : ctx->batches) {
+        const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
+        const int nl = b.n_local;
+        std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0), dst((size_t)std::max(nl, 1) * ist, 0);
+        std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
+        for (int el = 0; el < nl; ++el) {
+            const int e = b.first + el;
+            const int *id = b.idx.data() + (size_t)e * nn;
+            const int *ord = b.corner_perm.data() + (size_t)e * nn;
             for (int c = 0; c < nn; ++c) {
-                b.corner_perm[(size_t)e * nn + c] = ord[c];
                 const int pn = F.iperm[id[ord[c]]];
                 idx[(size_t)el * ist + c] = pn;
-                inc[pn].push_back((int)(slot + (int64_t)el * nn + c));
+                dst[(size_t)el * ist + c] = (int)inc_pos[pn]++;
             }
             const double *R = &b.rest[(size_t)e * 12];
             if (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) {
@@ -306,7 +317,7 @@ int upload_all(admm_hip_ctx *ctx) {
             w2h2[el] = (ctx->dt * ctx->dt) * (w * w);
             kbl[el] = b.params[(size_t)e * np] * b.measure[e];
         }
-        TRY(upload(ctx, &b.d_idx, idx)); TRY(upload(ctx, &b.d_rest, rest)); TRY(upload(ctx, &b.d_par, par));
+        TRY(upload(ctx, &b.d_idx, idx)); TRY(upload(ctx, &b.d_dst, dst)); TRY(upload(ctx, &b.d_rest, rest)); TRY(upload(ctx, &b.d_par, par));
         TRY(upload(ctx, &b.d_w2h2, w2h2)); TRY(upload(ctx, &b.d_kblend, kbl)); TRY(upload(ctx, &b.d_w2, w2));
         TRY(dalloc(ctx, &b.d_u, (size_t)rows * std::max(nl, 1))); TRY(dalloc(ctx, &b.d_z, (size_t)rows * std::max(nl, 1)));
         HIPCHK(hipMemset(b.d_u, 0, sizeof(double) * (size_t)rows * std::max(nl, 1)));
@@ -320,16 +331,11 @@ int upload_all(admm_hip_ctx *ctx) {
             for (int el = 0; el < nl; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)(b.first + el) + j]; ac[el] = b.active[b.first + el]; }
             TRY(upload(ctx, &b.d_targets, tg)); TRY(upload(ctx, &b.d_active, ac));
         }
-        slot += (int64_t)nl * nn; nloc += nl;
     }
     ctx->n_fslots = slot; ctx->info.n_elems_local = nloc;
     TRY(dalloc(ctx, &ctx->d_fslot, 3 * (size_t)std::max<int64_t>(slot, 1)));
     HIPCHK(hipMemset(ctx->d_fslot, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slot, 1)));
-    {
-        std::vector<int64_t> ptr(n + 1, 0); std::vector<int> sl; sl.reserve(slot);
-        for (int i = 0; i < n; ++i) { ptr[i + 1] = ptr[i] + (int64_t)inc[i].size(); sl.insert(sl.end(), inc[i].begin(), inc[i].end()); }
-        TRY(upload(ctx, &ctx->d_inc_ptr, ptr)); TRY(upload(ctx, &ctx->d_inc_slot, sl));
-    }
+    TRY(upload(ctx, &ctx->d_inc_ptr, inc_ptr));
     HIPCHK(hipDeviceSynchronize());
     ctx->info.t_upload_s = now_s() - t0;
     return ADMM_OK;
@@ -339,7 +345,7 @@ BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     BatchDev d{};
     d.n = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
     d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
-    d.fslot = ctx->d_fslot + 3 * (size_t)b.slot_base; d.targets = b.d_targets; d.active = b.d_active;
+    d.fslot = ctx->d_fslot; d.dst = b.d_dst; d.targets = b.d_targets; d.active = b.d_active;
     d.dx_override = b.d_dx_override;
     return d;
 }
@@ -348,7 +354,7 @@ FactorDev factor_dev(const admm_hip_ctx *ctx) {
     FactorDev f{};
     f.panels = ctx->d_panels; f.sn_first = ctx->d_sn_first; f.sn_ncols = ctx->d_sn_ncols; f.sn_nrows = ctx->d_sn_nrows;
     f.sn_panel_off = ctx->d_sn_panel_off; f.sn_rows_off = ctx->d_sn_rows_off; f.sn_slot_off = ctx->d_sn_slot_off;
-    f.rows = ctx->d_rows; f.gat_ptr = ctx->d_gat_ptr; f.gat_slot = ctx->d_gat_slot;
+    f.rows = ctx->d_rows; f.sn_front_off = ctx->d_sn_front_off; f.cg_ptr = ctx->d_cg_ptr; f.cg_slot = ctx->d_cg_slot;
     return f;
 }
 
@@ -388,7 +394,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
 
 int launch_rhs(admm_hip_ctx *ctx) {
     const int n3 = 3 * ctx->n_nodes;
-    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_inc_slot,
+    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr,
                        ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, ctx->d_y);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
@@ -401,7 +407,6 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     const int nl = (int)ctx->levels.size();
     for (int l = 0; l < nl; ++l) {
         const LevelDev &L = ctx->levels[l];
-        if (L.n_cols) hipLaunchKernelGGL(solve_gather_kernel, dim3((3 * L.n_cols + 255) / 256), dim3(256), 0, ctx->stream, L.n_cols, L.d_cols, F, ctx->d_y, ctx->d_c);
         if (L.n_small) hipLaunchKernelGGL(solve_fwd_small_kernel, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
         if (L.n_big) hipLaunchKernelGGL(solve_fwd_big_kernel, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
     }

@@ -183,16 +183,34 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F) {
     F.n_slots = soff; F.nnz_tri = nnz;
     F.levels.assign(maxlev + 1, std::vector<int>());
     for (int s = 0; s < ns; ++s) F.levels[F.sn[s].level].push_back(s);
-    // gather lists: for each column, the slots that feed it (ascending supernode)
-    F.gat_ptr.assign(n + 1, 0);
-    for (int64_t q = 0; q < roff; ++q) F.gat_ptr[F.rows[q] + 1]++;
-    for (int j = 0; j < n; ++j) F.gat_ptr[j + 1] += F.gat_ptr[j];
-    F.gat_slot.resize(roff);
+    // multifrontal gather lists: each child's contribution row lands on one front row of its parent
     {
-        std::vector<int64_t> pos(F.gat_ptr.begin(), F.gat_ptr.end() - 1);
-        for (int s = 0; s < ns; ++s) for (int q = 0; q < F.sn[s].nrows; ++q) {
-            int row = F.rows[F.sn[s].rows_off + q];
-            F.gat_slot[pos[row]++] = (int)(F.sn[s].slot_off + q);
+        int64_t foff = 0;
+        for (int s = 0; s < ns; ++s) { F.sn[s].front_off = foff; foff += F.sn[s].ncols + F.sn[s].nrows; }
+        F.cg_ptr.assign(foff + 1, 0);
+        std::vector<int64_t> target(roff, -1);
+        for (int c = 0; c < ns; ++c) {
+            const Supernode &C = F.sn[c];
+            if (C.parent < 0) continue;
+            const Supernode &P = F.sn[C.parent];
+            const int *prow = F.rows.data() + P.rows_off;
+            const int plast = P.first + P.ncols - 1;
+            for (int q = 0; q < C.nrows; ++q) {
+                const int g = F.rows[C.rows_off + q];
+                int i;
+                if (g <= plast) i = g - P.first;
+                else i = P.ncols + (int)(std::lower_bound(prow, prow + P.nrows, g) - prow);
+                target[C.rows_off + q] = P.front_off + i;
+                F.cg_ptr[P.front_off + i + 1]++;
+            }
+        }
+        for (int64_t i = 0; i < foff; ++i) F.cg_ptr[i + 1] += F.cg_ptr[i];
+        F.cg_slot.assign(F.cg_ptr[foff], 0);
+        std::vector<int64_t> pos(F.cg_ptr.begin(), F.cg_ptr.end() - 1);
+        for (int c = 0; c < ns; ++c) {               // ascending child index = fixed summation order
+            const Supernode &C = F.sn[c];
+            if (C.parent < 0) continue;
+            for (int q = 0; q < C.nrows; ++q) F.cg_slot[pos[target[C.rows_off + q]]++] = (int)(C.slot_off + q);
         }
     }
     F.panels.clear();
@@ -372,7 +390,7 @@ void panel_solve_host(const Factor &F, const double *b, double *x) {
             const int col = S.first + j;
             for (int c = 0; c < 3; ++c) {
                 double t = y[3 * (size_t)col + c];
-                for (int64_t g = F.gat_ptr[col]; g < F.gat_ptr[col + 1]; ++g) t -= C[3 * (size_t)F.gat_slot[g] + c];
+                for (int64_t g = F.cg_ptr[S.front_off + j]; g < F.cg_ptr[S.front_off + j + 1]; ++g) t -= C[3 * (size_t)F.cg_slot[g] + c];
                 y[3 * (size_t)col + c] = t;
             }
         }
@@ -381,7 +399,10 @@ void panel_solve_host(const Factor &F, const double *b, double *x) {
             const int jmax = i < k ? i : k - 1;
             for (int j = 0; j <= jmax; ++j) { double p = P[i + (size_t)f * j]; for (int c = 0; c < 3; ++c) acc[c] += p * y[3 * (size_t)(S.first + j) + c]; }
             if (i < k) for (int c = 0; c < 3; ++c) w[3 * (size_t)(S.first + i) + c] = acc[c];
-            else for (int c = 0; c < 3; ++c) C[3 * (size_t)(S.slot_off + i - k) + c] = acc[c];
+            else {
+                for (int64_t g = F.cg_ptr[S.front_off + i]; g < F.cg_ptr[S.front_off + i + 1]; ++g) for (int c = 0; c < 3; ++c) acc[c] += C[3 * (size_t)F.cg_slot[g] + c];
+                for (int c = 0; c < 3; ++c) C[3 * (size_t)(S.slot_off + i - k) + c] = acc[c];
+            }
         }
     }
     for (int s = ns - 1; s >= 0; --s) {

@@ -7,8 +7,9 @@
 //
 //   for every supernode s with columns C_s (k of them) and below-rows R_s (r):
 //       P_s = [ L_ss^-1 ; L_rs L_ss^-1 ]        ((k+r) x k, column-major)
-//   forward  (levels bottom-up):  t_s = b_s - sum of contributions into C_s
-//                                 [w_s ; c_s] = P_s t_s      (c_s -> slots)
+//   forward  (levels bottom-up):  t_s = b_s - (children's contributions landing on C_s)
+//                                 [w_s ; c_s] = P_s t_s ;  c_s += children's contributions
+//                                 landing on R_s (multifrontal pass-through)   (c_s -> slots)
 //   backward (levels top-down):   x_s = P_s^T [w_s ; -x(R_s)]
 //
 // Both sweeps are plain dense panel x vector products with 3 right-hand sides
@@ -32,6 +33,7 @@ struct Supernode {
     int64_t rows_off = 0;   // into Factor::rows
     int64_t panel_off = 0;  // into Factor::panels (doubles), ld = ncols + nrows
     int64_t slot_off = 0;   // first contribution slot
+    int64_t front_off = 0;  // index of the supernode's first front row (k + r rows) in the global front-row numbering
 };
 
 struct Factor {
@@ -41,8 +43,8 @@ struct Factor {
     std::vector<int> rows;                 // concatenated R_s (new indices, ascending)
     std::vector<double> panels;            // concatenated P_s
     std::vector<std::vector<int>> levels;  // supernodes per level (level 0 = leaves)
-    std::vector<int64_t> gat_ptr;          // per new column: range into gat_slot
-    std::vector<int> gat_slot;             // contribution slots feeding that column, ascending supernode
+    std::vector<int64_t> cg_ptr;           // per front row (front_off[s] + i): range into cg_slot
+    std::vector<int> cg_slot;              // the CHILDREN's contribution slots that land on that front row (child order)
     int64_t n_slots = 0;                   // sum of nrows
     int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
     int max_cols = 0, max_rows = 0;

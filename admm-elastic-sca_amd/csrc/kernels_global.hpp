@@ -43,18 +43,19 @@ __global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, dou
     x[i] = xc;
 }
 
-// One lane per dof: b = base + sum over the node's incident element corners of
-// the per-corner contributions written by the local kernels (fixed order:
-// batch, element, corner).  base = M x_bar on rank 0, 0 elsewhere, so that the
-// cross-rank sum of the partial right-hand sides is the full one.
-__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr, const int *__restrict__ inc_slot,
+// One lane per dof: b = base + sum of the node's incident per-corner
+// contributions.  The local kernels write every corner's 24 bytes straight to
+// its position in the node's incidence list (node-sorted slots), so this is a
+// contiguous streaming read in fixed (batch, element, corner) order.
+// base = M x_bar on rank 0, 0 elsewhere (the cross-rank sum is the full RHS).
+__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr,
                                   const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base, double *__restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n_nodes) return;
     const int node = i / 3, c = i - 3 * node;
     double acc = 0.0;
     const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
-    for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)inc_slot[p] + c];
+    for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
     y[i] = add_base ? (mxbar[i] + acc) : acc;
 }
 
@@ -64,27 +65,25 @@ __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_p
 struct FactorDev {
     const double *panels;
     const int *sn_first, *sn_ncols, *sn_nrows;
-    const int64_t *sn_panel_off, *sn_rows_off, *sn_slot_off;
+    const int64_t *sn_panel_off, *sn_rows_off, *sn_slot_off, *sn_front_off;
     const int *rows;
-    const int64_t *gat_ptr;
-    const int *gat_slot;
+    const int64_t *cg_ptr;   // per front row: children's contribution slots landing on it
+    const int *cg_slot;
 };
 
-// t = y - sum(contributions) for the columns of one level, in place.
-__global__ void solve_gather_kernel(int n_items, const int *__restrict__ cols, FactorDev F, double *__restrict__ y, const double *__restrict__ C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n_items) return;
-    const int it = i / 3, c = i - 3 * it;
-    const int col = cols[it];
-    double t = y[3 * (size_t)col + c];
-    for (int64_t g = F.gat_ptr[col]; g < F.gat_ptr[col + 1]; ++g) t -= C[3 * (size_t)F.gat_slot[g] + c];
-    y[3 * (size_t)col + c] = t;
+// sum of the children's contributions that land on front row `fr` (fixed child order)
+__device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const double *__restrict__ C, double &s0, double &s1, double &s2) {
+    s0 = 0.0; s1 = 0.0; s2 = 0.0;
+    for (int64_t g = F.cg_ptr[fr]; g < F.cg_ptr[fr + 1]; ++g) {
+        const double *c = C + 3 * (size_t)F.cg_slot[g];
+        s0 += c[0]; s1 += c[1]; s2 += c[2];
+    }
 }
 
 constexpr int FWD_SMALL_KMAX = 64;
 
 // Forward sweep, supernodes with k <= 64: one wave = one (supernode, 64-row tile);
-// lane = row of the panel; t_s staged per wave in LDS.
+// lane = row of the panel; t_s = y_s - children's contributions, staged per wave in LDS.
 __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const int *__restrict__ item_sn, const int *__restrict__ item_tile,
                                                               FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
     __shared__ double ts[4][FWD_SMALL_KMAX * 3];
@@ -92,10 +91,13 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     const int item = blockIdx.x * 4 + wave;
     const bool live = item < n_items;
     int s = 0, tile = 0, k = 0, r = 0, first = 0;
-    if (live) { s = item_sn[item]; tile = item_tile[item]; k = F.sn_ncols[s]; r = F.sn_nrows[s]; first = F.sn_first[s]; }
+    int64_t foff = 0;
+    if (live) { s = item_sn[item]; tile = item_tile[item]; k = F.sn_ncols[s]; r = F.sn_nrows[s]; first = F.sn_first[s]; foff = F.sn_front_off[s]; }
     if (live && lane < k) {
         const double *src = y + 3 * (size_t)(first + lane);
-        ts[wave][3 * lane] = src[0]; ts[wave][3 * lane + 1] = src[1]; ts[wave][3 * lane + 2] = src[2];
+        double c0, c1, c2;
+        child_sum(F, foff + lane, C, c0, c1, c2);
+        ts[wave][3 * lane] = src[0] - c0; ts[wave][3 * lane + 1] = src[1] - c1; ts[wave][3 * lane + 2] = src[2] - c2;
     }
     __syncthreads();
     if (!live) return;
@@ -119,8 +121,13 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
         const double *t = &ts[wave][3 * j];
         a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
     }
-    double *dst = (i < k) ? (W + 3 * (size_t)(first + i)) : (C + 3 * (size_t)(F.sn_slot_off[s] + (i - k)));
-    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+    if (i < k) { double *dst = W + 3 * (size_t)(first + i); dst[0] = a0; dst[1] = a1; dst[2] = a2; }
+    else {
+        double c0, c1, c2;
+        child_sum(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
+        double *dst = C + 3 * (size_t)(F.sn_slot_off[s] + (i - k));
+        dst[0] = a0 + c0; dst[1] = a1 + c1; dst[2] = a2 + c2;
+    }
 }
 
 // Forward sweep, supernodes with k > 64: one 1024-thread block = one
@@ -134,31 +141,38 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = item_sn[blockIdx.x], tile = item_tile[blockIdx.x];
     const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
+    const int64_t foff = F.sn_front_off[s];
     const int f = k + r;
     const int i = tile * 64 + lane;
     const bool row_ok = i < f;
     const double *P = F.panels + F.sn_panel_off[s] + (row_ok ? i : 0);
     const int jend = (i < k) ? i + 1 : k;
+    // columns beyond the tile's last row never contribute to a tile inside the triangle
+    const int kneed = min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int c0 = 0; c0 < k; c0 += FWD_BIG_KCHUNK) {
-        const int kc = min(FWD_BIG_KCHUNK, k - c0);
+    for (int c0 = 0; c0 < kneed; c0 += FWD_BIG_KCHUNK) {
+        const int kc = min(FWD_BIG_KCHUNK, kneed - c0);
         __syncthreads();
-        for (int q = threadIdx.x; q < 3 * kc; q += 1024) ts[q] = y[3 * (size_t)(first + c0) + q];
+        for (int q = threadIdx.x; q < kc; q += 1024) {
+            const double *src = y + 3 * (size_t)(first + c0 + q);
+            double s0, s1, s2;
+            child_sum(F, foff + c0 + q, C, s0, s1, s2);
+            ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
+        }
         __syncthreads();
-        // the tile's rows need columns < min(k, tile_last_row+1): skip chunks beyond
         const int per = (kc + 15) >> 4;
         const int jb = c0 + wave * per;
         int je = min(jb + per, c0 + kc);
         if (row_ok) {
             je = min(je, jend);
             int j = jb;
-            for (; j + 4 <= je; j += 4) {
-                const double p0 = P[(size_t)f * j], p1 = P[(size_t)f * (j + 1)], p2 = P[(size_t)f * (j + 2)], p3 = P[(size_t)f * (j + 3)];
+            for (; j + 8 <= je; j += 8) {
+                double p[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) p[q] = P[(size_t)f * (j + q)];
                 const double *t = &ts[3 * (j - c0)];
-                a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
-                a0 += p1 * t[3]; a1 += p1 * t[4]; a2 += p1 * t[5];
-                a0 += p2 * t[6]; a1 += p2 * t[7]; a2 += p2 * t[8];
-                a0 += p3 * t[9]; a1 += p3 * t[10]; a2 += p3 * t[11];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a0 += p[q] * t[3 * q]; a1 += p[q] * t[3 * q + 1]; a2 += p[q] * t[3 * q + 2]; }
             }
             for (; j < je; ++j) {
                 const double p0 = P[(size_t)f * j];
@@ -176,17 +190,21 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
             double acc = red[0][3 * ln + c];
 #pragma unroll
             for (int w = 1; w < 16; ++w) acc += red[w][3 * ln + c];
-            double *dst = (row < k) ? (W + 3 * (size_t)(first + row)) : (C + 3 * (size_t)(F.sn_slot_off[s] + (row - k)));
-            dst[c] = acc;
+            if (row < k) W[3 * (size_t)(first + row) + c] = acc;
+            else {
+                double carry = 0.0;
+                for (int64_t g = F.cg_ptr[foff + row]; g < F.cg_ptr[foff + row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c];
+                C[3 * (size_t)(F.sn_slot_off[s] + (row - k)) + c] = acc + carry;
+            }
         }
     }
 }
 
-// Backward sweep: one 256-thread block = (supernode, 16-column chunk); each
-// wave owns 4 columns; lanes stride over the rows of the panel column; the
-// vector [w_s ; -x(R_s)] is staged in LDS in row chunks.
-constexpr int BWD_COLS = 16;
-constexpr int BWD_RCHUNK = 2048;
+// Backward sweep: one 256-thread block = (supernode, 4 columns), one wave per
+// column; lanes stride over the rows of the (contiguous) panel column, 4 rows
+// per lane in flight; the vector [w_s ; -x(R_s)] is staged in LDS in row chunks.
+constexpr int BWD_COLS = 4;
+constexpr int BWD_RCHUNK = 1024;
 __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_chunk,
                                                         FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
     __shared__ double vs[BWD_RCHUNK * 3];
@@ -195,12 +213,11 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
     const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
     const int f = k + r;
     const int *rows = F.rows + F.sn_rows_off[s];
-    const double *P = F.panels + F.sn_panel_off[s];
     const int jc0 = chunk * BWD_COLS;           // first column of this block
-    const int jw = jc0 + wave * 4;              // first column of this wave
-    double acc[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { acc[q][0] = 0.0; acc[q][1] = 0.0; acc[q][2] = 0.0; }
+    const int j = jc0 + wave;                   // this wave's column
+    const bool col_ok = j < k;
+    const double *Pj = F.panels + F.sn_panel_off[s] + (size_t)f * (col_ok ? j : 0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     // rows < jc0 are never needed by this block (lower triangular diagonal block)
     for (int r0 = jc0; r0 < f; r0 += BWD_RCHUNK) {
         const int rc = min(BWD_RCHUNK, f - r0);
@@ -213,33 +230,26 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
             vs[3 * q] = v0; vs[3 * q + 1] = v1; vs[3 * q + 2] = v2;
         }
         __syncthreads();
-        for (int q = lane; q < rc; q += 64) {
-            const int i = r0 + q;
-            const double v0 = vs[3 * q], v1 = vs[3 * q + 1], v2 = vs[3 * q + 2];
+        if (col_ok) {
+            int q = lane;
+            for (; q + 192 < rc; q += 256) {
+                double p[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int j = jw + c;
-                if (j < k && i >= j) {
-                    const double p = P[i + (size_t)f * j];
-                    acc[c][0] += p * v0; acc[c][1] += p * v1; acc[c][2] += p * v2;
-                }
+                for (int u = 0; u < 4; ++u) { const int i = r0 + q + 64 * u; p[u] = (i >= j) ? Pj[i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double *v = &vs[3 * (q + 64 * u)]; a0 += p[u] * v[0]; a1 += p[u] * v[1]; a2 += p[u] * v[2]; }
+            }
+            for (; q < rc; q += 64) {
+                const int i = r0 + q;
+                if (i >= j) { const double p = Pj[i]; const double *v = &vs[3 * q]; a0 += p * v[0]; a1 += p * v[1]; a2 += p * v[2]; }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            double v = acc[c][d];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-            acc[c][d] = v;
-        }
-        const int j = jw + c;
-        if (lane == 0 && j < k) {
-            double *dst = X + 3 * (size_t)(first + j);
-            dst[0] = acc[c][0]; dst[1] = acc[c][1]; dst[2] = acc[c][2];
-        }
+    for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
+    if (lane == 0 && col_ok) {
+        double *dst = X + 3 * (size_t)(first + j);
+        dst[0] = a0; dst[1] = a1; dst[2] = a2;
     }
 }
 

@@ -22,8 +22,9 @@
 //   w2h2  f64 [n]           dt^2 * weight^2
 //   u, z  f64 SoA [rows][n]
 //   state f64 SoA [4][n]    (sigma warm start, L-BFGS init_hess)
-//   fslot f64 [n*nodes][3]  element-major per-corner contributions; staged
-//         through LDS so the 96 B per element leave the CU as full lines.
+//   fslot f64 [incidences][3]  per-corner contributions, NODE-sorted: every corner
+//         writes its 24 bytes to its position in the node's incidence list
+//         (dst, int32 [n][4]), so that the RHS kernel streams contiguously.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "local_math.hpp"
@@ -43,7 +44,8 @@ struct BatchDev {
     double *u, *z;         // SoA [rows][n]
     double *state;         // SoA [4][n]
     int *n_iters;          // [n]
-    double *fslot;         // [n*nodes][3]
+    double *fslot;         // [total incidences][3], node-sorted (see rhs_gather_kernel)
+    const int *dst;        // [n][stride]: slot of every corner in its node's incidence list
     double *targets;       // anchors: [n][3]
     const int *active;     // anchors: [n]
     const double *dx_override; // parity tests: SoA [rows][n] of D_i x to use instead of the gather (NULL in production)
@@ -80,11 +82,11 @@ __device__ __forceinline__ void store_block_contiguous(double *lds, const double
 // ---------------------------------------------------------------------------
 template <int KIND, int M>
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
-    __shared__ double lds[LOCAL_BLOCK * 13];
     const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    const bool live = e < n;
-    const int ec = live ? e : n - 1;
+    if (e >= n) return;
+    const bool live = true;
+    const int ec = e;
     double f[12];
     {
         const int4 id = reinterpret_cast<const int4 *>(b.idx)[ec];
@@ -148,9 +150,12 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tet_kernel(BatchDev b, co
             f[3 * c + 2] = s * ((B[c] * q.m20 + B[c + 4] * q.m21) + B[c + 8] * q.m22);
         }
     }
-    const int e0 = blockIdx.x * LOCAL_BLOCK;
-    const int n_valid = min(LOCAL_BLOCK, n - e0);
-    store_block_contiguous<12>(lds, f, b.fslot, e0, n_valid);
+    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
+    double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
+    o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2];
+    o1[0] = f[3]; o1[1] = f[4]; o1[2] = f[5];
+    o2[0] = f[6]; o2[1] = f[7]; o2[2] = f[8];
+    o3[0] = f[9]; o3[1] = f[10]; o3[2] = f[11];
 }
 
 // ---------------------------------------------------------------------------
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b,
         else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
         const double un = u + (dx - zi);
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
-        b.fslot[3 * (size_t)e + j] = s * (zi - un);
+        b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
     }
 }
 
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b,
         const double un = u[j] + (dx[j] - zi);
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
         const double f = s * (zi - un);
-        b.fslot[3 * (2 * (size_t)e) + j] = f;
-        b.fslot[3 * (2 * (size_t)e + 1) + j] = -f;
+        b.fslot[3 * (size_t)b.dst[2 * (size_t)e] + j] = f;
+        b.fslot[3 * (size_t)b.dst[2 * (size_t)e + 1] + j] = -f;
     }
 }
 
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, c
             f[r] = s * (zi - un);
         }
         // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
-        b.fslot[3 * (4 * (size_t)e + 0) + j] = f[0];
-        b.fslot[3 * (4 * (size_t)e + 1) + j] = f[2];
-        b.fslot[3 * (4 * (size_t)e + 2) + j] = -((f[0] + f[1]) + f[2]);
-        b.fslot[3 * (4 * (size_t)e + 3) + j] = f[1];
+        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 0] + j] = f[0];
+        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 1] + j] = f[2];
+        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 2] + j] = -((f[0] + f[1]) + f[2]);
+        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 3] + j] = f[1];
     }
 }
 
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) b.fslot[3 * (3 * (size_t)e + c) + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
+        for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)b.dst[4 * (size_t)e + c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
 }
 
 } // namespace admm_dev
