@@ -65,9 +65,10 @@ def lib():
     """Loads libadmm_hip.so (building it if absent).  Raises if it cannot be loaded."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("ADMM_HIP_LIB", LIB_PATH)   # experimental variants (tools/ab_local.py)
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.admm_hip_last_error.restype = C.c_char_p
         L.admm_hip_last_error.argtypes = [C.c_void_p]
         L.admm_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]

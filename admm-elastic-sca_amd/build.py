@@ -17,8 +17,12 @@ OUT = os.path.join(HERE, "libadmm_hip.so")
 OBJ = os.path.join(HERE, "_build")
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wno-unknown-pragmas"]
+# -disable-promote-alloca-to-vector keeps the L-BFGS history (a run-time indexed
+# private array, local_math.hpp) in scratch instead of 80 VGPRs: measured -15 % on
+# the tet kernel together with __launch_bounds__(256, 3) (tools/ab_local.py).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
-             "-Wno-unused-function", "-Wno-unused-result"]
+             "-Wno-unused-function", "-Wno-unused-result", "-Wno-comment", "-Wno-bitwise-instead-of-logical",
+             "-mllvm", "-disable-promote-alloca-to-vector"]
 
 
 def _newer(src_list, target):
@@ -28,7 +32,10 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_hip_flags=(), out=None, tag=""):
+    """extra_hip_flags/out/tag build an experimental variant next to the default library."""
+    global OUT
+    out = out or OUT
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
@@ -36,7 +43,7 @@ def build(force=False, verbose=False):
     jobs = [
         (["g++"] + HOST_FLAGS + ["-mavx2", "-mfma"], "dense.cpp", "dense.o"),
         (["g++"] + HOST_FLAGS, "factor.cpp", "factor.o"),
-        ([hipcc] + HIP_FLAGS, "admm_hip.hip", "admm_hip.o"),
+        ([hipcc] + HIP_FLAGS + list(extra_hip_flags), "admm_hip.hip", "admm_hip%s.o" % tag),
     ]
     objs = []
     rebuilt = False
@@ -48,14 +55,14 @@ def build(force=False, verbose=False):
             full = cmd + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(full))
-            subprocess.check_call(full)
+            subprocess.check_call(full, stderr=subprocess.DEVNULL if not verbose else None)
             rebuilt = True
-    if rebuilt or not os.path.exists(OUT):
-        full = [hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs + ["-lgomp"]
+    if rebuilt or not os.path.exists(out):
+        full = [hipcc, "--offload-arch=gfx950", "-shared", "-o", out] + objs + ["-lgomp"]
         if verbose:
             print(" ".join(full))
-        subprocess.check_call(full)
-    return OUT
+        subprocess.check_call(full, stderr=subprocess.DEVNULL if not verbose else None)
+    return out
 
 
 if __name__ == "__main__":

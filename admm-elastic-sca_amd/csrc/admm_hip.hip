@@ -78,7 +78,7 @@ struct admm_hip_ctx {
     double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
     double *d_fslot = nullptr; int64_t n_fslots = 0;
     int64_t *d_inc_ptr = nullptr;
-    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr;
+    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr, *d_cg2 = nullptr;
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
@@ -205,6 +205,13 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
     ctx->info.n_levels = (int64_t)F.levels.size();
     ctx->info.max_super_cols = F.max_cols; ctx->info.max_super_rows = F.max_rows;
     ctx->info.solve_contrib_rows = F.n_slots;
+    if (getenv("ADMM_HIP_VERBOSE")) {
+        for (size_t l = 0; l < F.levels.size(); ++l) {
+            int64_t e = 0, rws = 0; int mk = 0, small = 0;
+            for (int s : F.levels[l]) { const Supernode &S = F.sn[s]; e += (int64_t)S.ncols * (S.ncols + 1) / 2 + (int64_t)S.nrows * S.ncols; rws += S.ncols + S.nrows; mk = std::max(mk, S.ncols); small += S.ncols <= 64; }
+            fprintf(stderr, "admm_hip: level %2zu: %6zu supernodes (%d with k<=64), max k %4d, front rows %8lld, entries %10lld (%.1f MB)\n", l, F.levels[l].size(), small, mk, (long long)rws, (long long)e, e * 8e-6);
+        }
+    }
     ctx->info.t_order_s = F.t_order; ctx->info.t_symbolic_s = F.t_symbolic; ctx->info.t_numeric_s = F.t_numeric;
     return ADMM_OK;
 }
@@ -228,6 +235,8 @@ int upload_factor(admm_hip_ctx *ctx) {
     TRY(upload(ctx, &ctx->d_rows, F.rows));
     TRY(upload(ctx, &ctx->d_sn_front_off, foff));
     TRY(upload(ctx, &ctx->d_cg_ptr, F.cg_ptr)); TRY(upload(ctx, &ctx->d_cg_slot, F.cg_slot));
+    ctx->d_cg2 = nullptr;
+    if (!F.cg2.empty()) TRY(upload(ctx, &ctx->d_cg2, F.cg2));
     TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
     ctx->levels.assign(F.levels.size(), LevelDev());
     for (size_t l = 0; l < F.levels.size(); ++l) {
@@ -354,7 +363,7 @@ FactorDev factor_dev(const admm_hip_ctx *ctx) {
     FactorDev f{};
     f.panels = ctx->d_panels; f.sn_first = ctx->d_sn_first; f.sn_ncols = ctx->d_sn_ncols; f.sn_nrows = ctx->d_sn_nrows;
     f.sn_panel_off = ctx->d_sn_panel_off; f.sn_rows_off = ctx->d_sn_rows_off; f.sn_slot_off = ctx->d_sn_slot_off;
-    f.rows = ctx->d_rows; f.sn_front_off = ctx->d_sn_front_off; f.cg_ptr = ctx->d_cg_ptr; f.cg_slot = ctx->d_cg_slot;
+    f.rows = ctx->d_rows; f.sn_front_off = ctx->d_sn_front_off; f.cg_ptr = ctx->d_cg_ptr; f.cg_slot = ctx->d_cg_slot; f.cg2 = (const int2 *)ctx->d_cg2;
     return f;
 }
 
@@ -407,8 +416,14 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     const int nl = (int)ctx->levels.size();
     for (int l = 0; l < nl; ++l) {
         const LevelDev &L = ctx->levels[l];
-        if (L.n_small) hipLaunchKernelGGL(solve_fwd_small_kernel, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
-        if (L.n_big) hipLaunchKernelGGL(solve_fwd_big_kernel, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+        if (L.n_small) {
+            if (F.cg2) hipLaunchKernelGGL(solve_fwd_small_kernel<true>, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL(solve_fwd_small_kernel<false>, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+        }
+        if (L.n_big) {
+            if (F.cg2) hipLaunchKernelGGL(solve_fwd_big_kernel<true>, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL(solve_fwd_big_kernel<false>, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+        }
     }
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
     for (int l = nl - 1; l >= 0; --l) {

@@ -212,6 +212,13 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F) {
             if (C.parent < 0) continue;
             for (int q = 0; q < C.nrows; ++q) F.cg_slot[pos[target[C.rows_off + q]]++] = (int)(C.slot_off + q);
         }
+        bool two = true;
+        for (int64_t i = 0; i < foff && two; ++i) two = (F.cg_ptr[i + 1] - F.cg_ptr[i]) <= 2;
+        F.cg2.clear();
+        if (two) {
+            F.cg2.assign(2 * (size_t)foff, -1);
+            for (int64_t i = 0; i < foff; ++i) for (int64_t g = F.cg_ptr[i]; g < F.cg_ptr[i + 1]; ++g) F.cg2[2 * i + (g - F.cg_ptr[i])] = F.cg_slot[g];
+        }
     }
     F.panels.clear();
     F.t_symbolic = now_s() - t1;

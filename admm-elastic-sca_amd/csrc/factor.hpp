@@ -45,6 +45,7 @@ struct Factor {
     std::vector<std::vector<int>> levels;  // supernodes per level (level 0 = leaves)
     std::vector<int64_t> cg_ptr;           // per front row (front_off[s] + i): range into cg_slot
     std::vector<int> cg_slot;              // the CHILDREN's contribution slots that land on that front row (child order)
+    std::vector<int> cg2;                  // [front rows][2]: the same lists when no row has more than 2 entries (-1 = none), else empty
     int64_t n_slots = 0;                   // sum of nrows
     int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
     int max_cols = 0, max_rows = 0;

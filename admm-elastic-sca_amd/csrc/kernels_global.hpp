@@ -69,14 +69,22 @@ struct FactorDev {
     const int *rows;
     const int64_t *cg_ptr;   // per front row: children's contribution slots landing on it
     const int *cg_slot;
+    const int2 *cg2;         // same lists as fixed pairs (binary elimination trees), or NULL
 };
 
 // sum of the children's contributions that land on front row `fr` (fixed child order)
+template <bool CG2>
 __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const double *__restrict__ C, double &s0, double &s1, double &s2) {
     s0 = 0.0; s1 = 0.0; s2 = 0.0;
-    for (int64_t g = F.cg_ptr[fr]; g < F.cg_ptr[fr + 1]; ++g) {
-        const double *c = C + 3 * (size_t)F.cg_slot[g];
-        s0 += c[0]; s1 += c[1]; s2 += c[2];
+    if (CG2) {
+        const int2 ab = F.cg2[fr];
+        if (ab.x >= 0) { const double *c = C + 3 * (size_t)ab.x; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+        if (ab.y >= 0) { const double *c = C + 3 * (size_t)ab.y; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+    } else {
+        for (int64_t g = F.cg_ptr[fr]; g < F.cg_ptr[fr + 1]; ++g) {
+            const double *c = C + 3 * (size_t)F.cg_slot[g];
+            s0 += c[0]; s1 += c[1]; s2 += c[2];
+        }
     }
 }
 
@@ -84,6 +92,10 @@ constexpr int FWD_SMALL_KMAX = 64;
 
 // Forward sweep, supernodes with k <= 64: one wave = one (supernode, 64-row tile);
 // lane = row of the panel; t_s = y_s - children's contributions, staged per wave in LDS.
+// Everything that does not depend on t_s (the pass-through carry of the lane's own
+// row, the first panel columns) is requested before the staging barrier so that the
+// dependent index -> slot -> value chain overlaps with the panel stream.
+template <bool CG2>
 __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const int *__restrict__ item_sn, const int *__restrict__ item_tile,
                                                               FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
     __shared__ double ts[4][FWD_SMALL_KMAX * 3];
@@ -93,21 +105,31 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     int s = 0, tile = 0, k = 0, r = 0, first = 0;
     int64_t foff = 0;
     if (live) { s = item_sn[item]; tile = item_tile[item]; k = F.sn_ncols[s]; r = F.sn_nrows[s]; first = F.sn_first[s]; foff = F.sn_front_off[s]; }
-    if (live && lane < k) {
-        const double *src = y + 3 * (size_t)(first + lane);
-        double c0, c1, c2;
-        child_sum(F, foff + lane, C, c0, c1, c2);
-        ts[wave][3 * lane] = src[0] - c0; ts[wave][3 * lane + 1] = src[1] - c1; ts[wave][3 * lane + 2] = src[2] - c2;
-    }
-    __syncthreads();
-    if (!live) return;
     const int f = k + r;
     const int i = tile * 64 + lane;
-    if (i >= f) return;
-    const double *P = F.panels + F.sn_panel_off[s] + i;
-    const int jend = (i < k) ? i + 1 : k;
+    const bool row_ok = live && i < f;
+    const double *P = F.panels + (live ? F.sn_panel_off[s] : 0) + (row_ok ? i : 0);
+    const int jend = row_ok ? ((i < k) ? i + 1 : k) : 0;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (row_ok && i >= k) child_sum<CG2>(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
+    double pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] = (q < jend) ? P[(size_t)f * q] : 0.0;
+    if (live && lane < k) {
+        const double *src = y + 3 * (size_t)(first + lane);
+        double s0, s1, s2;
+        child_sum<CG2>(F, foff + lane, C, s0, s1, s2);
+        ts[wave][3 * lane] = src[0] - s0; ts[wave][3 * lane + 1] = src[1] - s1; ts[wave][3 * lane + 2] = src[2] - s2;
+    }
+    __syncthreads();
+    if (!row_ok) return;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    int j = 0;
+    {
+        const double *t = &ts[wave][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < jend) { a0 += pre[q] * t[3 * q]; a1 += pre[q] * t[3 * q + 1]; a2 += pre[q] * t[3 * q + 2]; }
+    }
+    int j = 4;
     for (; j + 4 <= jend; j += 4) {
         const double p0 = P[(size_t)f * j], p1 = P[(size_t)f * (j + 1)], p2 = P[(size_t)f * (j + 2)], p3 = P[(size_t)f * (j + 3)];
         const double *t = &ts[wave][3 * j];
@@ -123,8 +145,6 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     }
     if (i < k) { double *dst = W + 3 * (size_t)(first + i); dst[0] = a0; dst[1] = a1; dst[2] = a2; }
     else {
-        double c0, c1, c2;
-        child_sum(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
         double *dst = C + 3 * (size_t)(F.sn_slot_off[s] + (i - k));
         dst[0] = a0 + c0; dst[1] = a1 + c1; dst[2] = a2 + c2;
     }
@@ -134,6 +154,7 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
 // (supernode, 64-row tile); the 16 waves split the columns, partial sums are
 // combined through LDS in wave order.
 constexpr int FWD_BIG_KCHUNK = 2048;
+template <bool CG2>
 __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_tile,
                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
     __shared__ double ts[FWD_BIG_KCHUNK * 3];
@@ -149,36 +170,58 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
     const int jend = (i < k) ? i + 1 : k;
     // columns beyond the tile's last row never contribute to a tile inside the triangle
     const int kneed = min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
+    // the carry of the tile's rows does not depend on this supernode: request it first
+    double carry = 0.0;
+    if (threadIdx.x < 192) {
+        const int ln = threadIdx.x / 3, c = threadIdx.x - 3 * ln;
+        const int row = tile * 64 + ln;
+        if (row < f && row >= k) {
+            if (CG2) {
+                const int2 ab = F.cg2[foff + row];
+                if (ab.x >= 0) carry += C[3 * (size_t)ab.x + c];
+                if (ab.y >= 0) carry += C[3 * (size_t)ab.y + c];
+            } else {
+                for (int64_t g = F.cg_ptr[foff + row]; g < F.cg_ptr[foff + row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c];
+            }
+        }
+    }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int c0 = 0; c0 < kneed; c0 += FWD_BIG_KCHUNK) {
         const int kc = min(FWD_BIG_KCHUNK, kneed - c0);
+        const int per = (kc + 15) >> 4;
+        const int jb = c0 + wave * per;
+        int je = min(jb + per, c0 + kc);
+        je = row_ok ? min(je, jend) : jb;
+        // first group of this wave's panel columns in flight before the staging barrier
+        double pre[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[q] = (jb + q < je) ? P[(size_t)f * (jb + q)] : 0.0;
         __syncthreads();
         for (int q = threadIdx.x; q < kc; q += 1024) {
             const double *src = y + 3 * (size_t)(first + c0 + q);
             double s0, s1, s2;
-            child_sum(F, foff + c0 + q, C, s0, s1, s2);
+            child_sum<CG2>(F, foff + c0 + q, C, s0, s1, s2);
             ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
         }
         __syncthreads();
-        const int per = (kc + 15) >> 4;
-        const int jb = c0 + wave * per;
-        int je = min(jb + per, c0 + kc);
-        if (row_ok) {
-            je = min(je, jend);
-            int j = jb;
-            for (; j + 8 <= je; j += 8) {
-                double p[8];
+        {
+            const double *t = &ts[3 * (jb - c0)];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) p[q] = P[(size_t)f * (j + q)];
-                const double *t = &ts[3 * (j - c0)];
+            for (int q = 0; q < 8; ++q) if (jb + q < je) { a0 += pre[q] * t[3 * q]; a1 += pre[q] * t[3 * q + 1]; a2 += pre[q] * t[3 * q + 2]; }
+        }
+        int j = jb + 8;
+        for (; j + 8 <= je; j += 8) {
+            double p[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { a0 += p[q] * t[3 * q]; a1 += p[q] * t[3 * q + 1]; a2 += p[q] * t[3 * q + 2]; }
-            }
-            for (; j < je; ++j) {
-                const double p0 = P[(size_t)f * j];
-                const double *t = &ts[3 * (j - c0)];
-                a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
-            }
+            for (int q = 0; q < 8; ++q) p[q] = P[(size_t)f * (j + q)];
+            const double *t = &ts[3 * (j - c0)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a0 += p[q] * t[3 * q]; a1 += p[q] * t[3 * q + 1]; a2 += p[q] * t[3 * q + 2]; }
+        }
+        for (; j < je; ++j) {
+            const double p0 = P[(size_t)f * j];
+            const double *t = &ts[3 * (j - c0)];
+            a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
         }
     }
     red[wave][3 * lane] = a0; red[wave][3 * lane + 1] = a1; red[wave][3 * lane + 2] = a2;
@@ -191,11 +234,7 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
 #pragma unroll
             for (int w = 1; w < 16; ++w) acc += red[w][3 * ln + c];
             if (row < k) W[3 * (size_t)(first + row) + c] = acc;
-            else {
-                double carry = 0.0;
-                for (int64_t g = F.cg_ptr[foff + row]; g < F.cg_ptr[foff + row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c];
-                C[3 * (size_t)(F.sn_slot_off[s] + (row - k)) + c] = acc + carry;
-            }
+            else C[3 * (size_t)(F.sn_slot_off[s] + (row - k)) + c] = acc + carry;
         }
     }
 }

@@ -32,6 +32,9 @@
 namespace admm_dev {
 
 constexpr int LOCAL_BLOCK = 256;
+#ifndef ADMM_TET_WAVES
+#define ADMM_TET_WAVES 3   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
+#endif
 
 struct BatchDev {
     int n;                 // local elements
@@ -81,7 +84,12 @@ __device__ __forceinline__ void store_block_contiguous(double *lds, const double
 //       2 = LinearTetStrain (:127-153), 3 = TetVolume (:173-210)
 // ---------------------------------------------------------------------------
 template <int KIND, int M>
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
+#if ADMM_TET_WAVES > 0
+__global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
+#else
+__global__ __launch_bounds__(LOCAL_BLOCK)
+#endif
+void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
     const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= n) return;

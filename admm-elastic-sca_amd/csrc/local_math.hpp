@@ -22,6 +22,13 @@
 #define ADMM_HD inline
 #endif
 
+#ifndef ADMM_REUSE_GRAD
+#define ADMM_REUSE_GRAD 1   // reuse bitwise-identical gradient evaluations (see mt_linesearch)
+#endif
+#ifndef ADMM_HISTORY_REG
+#define ADMM_HISTORY_REG 0  // 1: L-BFGS history in registers, 0: in private (scratch) memory
+#endif
+
 namespace admm_dev {
 
 // libstdc++ std::min / std::max (second argument wins only on strict compare;
@@ -329,10 +336,15 @@ ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &
 
 // ---- MoreThuente::linesearch + cvsrch, morethuente.h:25-167 ------------------
 // x: base point, s: direction (= -q).  Returns the step length.
-template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, const V3 &s, double alpha_init) {
+// g_at_x is the gradient at x (the reference re-evaluates it, morethuente.h:31-33:
+// same input, same value -- reused here); g_out/evaluated return the gradient at
+// the accepted point x + stp*s when the search evaluated it (the caller's next
+// gradient(x0) is at bitwise the same point: x0 - rate*q == x + stp*(-q)).
+template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, const V3 &s, double alpha_init, const V3 &g_at_x, V3 &g_out, bool &evaluated) {
     double stp = alpha_init;
+    evaluated = false;
     double f = prob.value(x);
-    V3 g = prob.gradient(x);
+    V3 g = ADMM_REUSE_GRAD ? g_at_x : prob.gradient(x);
     int info = 0, infoc = 1;
     const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
     const int maxfev = 20;
@@ -353,6 +365,7 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         V3 xn; xn.a = x.a + stp * s.a; xn.b = x.b + stp * s.b; xn.c = x.c + stp * s.c;
         f = prob.value(xn);
         g = prob.gradient(xn);
+        g_out = g; evaluated = true;
         nfev++;
         double dg = dotd(g, s);
         double ftest1 = finit + stp * dgtest;
@@ -388,9 +401,82 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
 }
 
 // ---- cppoptlib::lbfgssolver<double>::minimize, OPT/solver/lbfgssolver.h:43-144
+// M = compile-time history capacity (>= min(maxIter,10)).  The history is a
+// run-time indexed private array on purpose: it lives in scratch memory, not in
+// VGPRs (it is only touched from the second outer iteration on, and keeping
+// 2*3*M + 2*M doubles in registers would halve the kernel's occupancy).
+template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int maxIter, double gradTol, double &init_hess) {
+    const int m_ = maxIter < 10 ? maxIter : 10;
+    const double eps_g = gradTol, eps_x = 1e-8;
+    double hs[M][3], hy[M][3], alpha[M], rho[M];
+    V3 grad = prob.gradient(x0);
+    double gamma_k = init_hess;
+    double alpha_init = smin(1.0, 1.0 / absmax(grad));
+    int globIter = 0;
+    int maxiter = maxIter;
+    double new_hess_guess = 1.0;
+    for (int k = 0; k < maxiter; k++) {
+        V3 x_old = x0, grad_old = grad, q = grad;
+        globIter++;
+        const int iter = m_ < k ? m_ : k;
+#pragma unroll 1
+        for (int i = iter - 1; i >= 0; --i) {
+            V3 si, yi; si.a = hs[i][0]; si.b = hs[i][1]; si.c = hs[i][2]; yi.a = hy[i][0]; yi.b = hy[i][1]; yi.c = hy[i][2];
+            const double r = 1.0 / dotd(si, yi);
+            const double al = r * dotd(si, q);
+            rho[i] = r; alpha[i] = al;
+            q.a = q.a - al * yi.a; q.b = q.b - al * yi.b; q.c = q.c - al * yi.c;
+        }
+        q.a = gamma_k * q.a; q.b = gamma_k * q.b; q.c = gamma_k * q.c;
+#pragma unroll 1
+        for (int i = 0; i < iter; ++i) {
+            V3 si, yi; si.a = hs[i][0]; si.b = hs[i][1]; si.c = hs[i][2]; yi.a = hy[i][0]; yi.b = hy[i][1]; yi.c = hy[i][2];
+            const double beta = rho[i] * dotd(q, yi);
+            const double ab = alpha[i] - beta;
+            q.a = q.a + ab * si.a; q.b = q.b + ab * si.b; q.c = q.c + ab * si.c;
+        }
+        double dir = dotd(q, grad);
+        if (dir < 1e-4) {
+            q = grad;
+            maxiter -= k;
+            k = 0;
+            alpha_init = smin(1.0, 1.0 / absmax(grad));
+        }
+        V3 mq; mq.a = -q.a; mq.b = -q.b; mq.c = -q.c;
+        V3 g_new; bool have_g;
+        const double rate = mt_linesearch(prob, x0, mq, alpha_init, grad, g_new, have_g);
+        x0.a = x0.a - rate * q.a; x0.b = x0.b - rate * q.b; x0.c = x0.c - rate * q.c;
+        V3 dxx; dxx.a = x_old.a - x0.a; dxx.b = x_old.b - x0.b; dxx.c = x_old.c - x0.c;
+        if (dotd(dxx, dxx) < eps_x) break;
+        grad = (ADMM_REUSE_GRAD && have_g) ? g_new : prob.gradient(x0);
+        double gradNorm = absmax(grad);
+        if (gradNorm < eps_g) { new_hess_guess = gamma_k; break; }
+        V3 s_temp, y_temp;
+        s_temp.a = x0.a - x_old.a; s_temp.b = x0.b - x_old.b; s_temp.c = x0.c - x_old.c;
+        y_temp.a = grad.a - grad_old.a; y_temp.b = grad.b - grad_old.b; y_temp.c = grad.c - grad_old.c;
+        if (k < m_) {
+            hs[k][0] = s_temp.a; hs[k][1] = s_temp.b; hs[k][2] = s_temp.c;
+            hy[k][0] = y_temp.a; hy[k][1] = y_temp.b; hy[k][2] = y_temp.c;
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < m_ - 1; ++i) {
+                hs[i][0] = hs[i + 1][0]; hs[i][1] = hs[i + 1][1]; hs[i][2] = hs[i + 1][2];
+                hy[i][0] = hy[i + 1][0]; hy[i][1] = hy[i + 1][1]; hy[i][2] = hy[i + 1][2];
+            }
+            hs[m_ - 1][0] = s_temp.a; hs[m_ - 1][1] = s_temp.b; hs[m_ - 1][2] = s_temp.c;
+            hy[m_ - 1][0] = y_temp.a; hy[m_ - 1][1] = y_temp.b; hy[m_ - 1][2] = y_temp.c;
+        }
+        gamma_k = dotd(s_temp, y_temp) / dotd(y_temp, y_temp);
+        alpha_init = 1.0;
+    }
+    init_hess = new_hess_guess;
+    return globIter;
+}
+
+// ---- variant with the history in registers (unrolled selects)
 // M = compile-time history capacity (>= min(maxIter,10)); history lives in
 // registers, run-time positions are resolved by unrolled selects.
-template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int maxIter, double gradTol, double &init_hess) {
+template <int M, class P> ADMM_HD int lbfgs_minimize_reg(const P &prob, V3 &x0, int maxIter, double gradTol, double &init_hess) {
     const int m_ = maxIter < 10 ? maxIter : 10;
     const double eps_g = gradTol, eps_x = 1e-8;
     V3 s[M], y[M];
@@ -432,11 +518,12 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
             alpha_init = smin(1.0, 1.0 / absmax(grad));
         }
         V3 mq; mq.a = -q.a; mq.b = -q.b; mq.c = -q.c;
-        const double rate = mt_linesearch(prob, x0, mq, alpha_init);
+        V3 g_new; bool have_g;
+        const double rate = mt_linesearch(prob, x0, mq, alpha_init, grad, g_new, have_g);
         x0.a = x0.a - rate * q.a; x0.b = x0.b - rate * q.b; x0.c = x0.c - rate * q.c;
         V3 dxx; dxx.a = x_old.a - x0.a; dxx.b = x_old.b - x0.b; dxx.c = x_old.c - x0.c;
         if (dotd(dxx, dxx) < eps_x) break;
-        grad = prob.gradient(x0);
+        grad = (ADMM_REUSE_GRAD && have_g) ? g_new : prob.gradient(x0);
         double gradNorm = absmax(grad);
         if (gradNorm < eps_g) { new_hess_guess = gamma_k; break; }
         V3 s_temp, y_temp;
@@ -471,7 +558,11 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     V3 x2; x2.a = sa; x2.b = sb; x2.c = sc;
     if (x2.c < 0.0) x2.c *= -1.0;
     else if (fabs(x2.a) < 1.e-3 && fabs(x2.b) < 1.e-3 && fabs(x2.c) < 1.e-3) { x2.a = 1.e-3; x2.b = 1.e-3; x2.c = 1.e-3; }
+#if ADMM_HISTORY_REG
+    n_iters = lbfgs_minimize_reg<M>(P, x2, maxIter, 1e-8, hess);
+#else
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
+#endif
     sa = x2.a; sb = x2.b; sc = x2.c;
     return recompose(U, x2.a, x2.b, x2.c, V);
 }
