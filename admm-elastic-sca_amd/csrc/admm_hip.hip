@@ -568,6 +568,15 @@ int admm_hip_finalize(admm_hip_ctx *ctx) {
     TRY(host_assemble(ctx, false));
     TRY(host_factor(ctx, false));
     ctx->info.rank = ctx->rank; ctx->info.world = ctx->world;
+    {   // contiguous element ranges per batch (reference order preserved inside a rank)
+        int64_t nloc = 0;
+        for (Batch &b : ctx->batches) {
+            b.first = (int)((int64_t)b.n_total * ctx->rank / ctx->world);
+            b.n_local = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world) - b.first;
+            nloc += b.n_local;
+        }
+        ctx->info.n_elems_local = nloc;
+    }
     if (ctx->device_id >= 0) TRY(upload_all(ctx));
     ctx->finalized = true;
     return ADMM_OK;
