@@ -65,6 +65,13 @@ def lib():
     """Loads libadmm_hip.so (building it if absent).  Raises if it cannot be loaded."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64; importing it
+        # first makes libadmm_hip.so bind to that copy (same SONAME) so that streams and
+        # device pointers can be shared with torch.distributed (bench.py, tests).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         path = os.environ.get("ADMM_HIP_LIB", LIB_PATH)   # experimental variants (tools/ab_local.py)
         if not os.path.exists(path):
             build()

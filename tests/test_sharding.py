@@ -146,4 +146,6 @@ def test_two_shards_on_one_gpu(pkg):
         assert not errs, errs
         x0, x1, xr = shards[0].m_x, shards[1].m_x, ref.m_x
         assert np.array_equal(x0, x1)                      # replicated solve: identical on every rank
-        assert np.abs(x0 - xr).max() < 1e-11               # = unsharded, up to the order of the fp64 partial sums
+        # = unsharded, up to the order of the fp64 partial sums (first frame: rounding only;
+        # later frames: amplified by the truncated prox)
+        assert np.abs(x0 - xr).max() < (1e-11 if frame == 0 else 1e-6)
