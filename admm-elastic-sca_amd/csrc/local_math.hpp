@@ -35,6 +35,9 @@ namespace admm_dev {
 // this fixes what happens with NaNs exactly like the reference build)
 ADMM_HD double smin(double a, double b) { return (b < a) ? b : a; }
 ADMM_HD double smax(double a, double b) { return (a < b) ? b : a; }
+// x / |x| without the divide: IEEE division of a finite non-zero x by its own magnitude is exactly +-1
+// (0/0, inf/inf and NaN give NaN, as the divide would)
+ADMM_HD double unit_sign(double x) { return (x != 0.0 && fabs(x) <= DBL_MAX) ? copysign(1.0, x) : (x - x) / (x - x); }
 
 constexpr double kFltMax = 3.40282346638528859811704183484516925e+38; // (double)FLT_MAX
 
@@ -120,7 +123,7 @@ template <int P, int Q> ADMM_HD bool jacobi_pq(Mat3 &W, Mat3 &U, Mat3 &V) {
         double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
         double sign_t = tt > 0.0 ? 1.0 : -1.0;
         double n = 1.0 / sqrt(tt * tt + 1.0);
-        rs = -sign_t * (m01 / fabs(m01)) * fabs(tt) * n;
+        rs = -sign_t * unit_sign(m01) * fabs(tt) * n;
         rc = n;
     }
     double os = -rs;
@@ -161,9 +164,9 @@ ADMM_HD void svd3(const Mat3 &F, Mat3 &U, double &s0, double &s1, double &s2, Ma
         finished = !(a || b || c);
     }
     double a0 = fabs(W.m00), a1 = fabs(W.m11), a2 = fabs(W.m22);
-    if (a0 != 0.0) scale_col<0>(U, W.m00 / a0);
-    if (a1 != 0.0) scale_col<1>(U, W.m11 / a1);
-    if (a2 != 0.0) scale_col<2>(U, W.m22 / a2);
+    if (a0 != 0.0) scale_col<0>(U, unit_sign(W.m00));
+    if (a1 != 0.0) scale_col<1>(U, unit_sign(W.m11));
+    if (a2 != 0.0) scale_col<2>(U, unit_sign(W.m22));
     s0 = a0; s1 = a1; s2 = a2;
     // descending sort, first maximum wins (EIG/SVD/JacobiSVD.h:910-926); a zero
     // maximum ends the loop
@@ -260,7 +263,7 @@ ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &
     info = 0;
     bool bound = false;
     if ((brackt & ((stp <= smin(stx, sty)) | (stp >= smax(stx, sty)))) | (dx * (stp - stx) >= 0.0) | (stpmax < stpmin)) return;
-    double sgnd = dp * (dx / fabs(dx));
+    double sgnd = dp * unit_sign(dx);
     double stpf = 0, stpc = 0, stpq = 0;
     if (fp > fx) {
         info = 1; bound = true;
