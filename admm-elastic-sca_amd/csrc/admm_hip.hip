@@ -51,7 +51,7 @@ struct Batch {
 struct LevelDev {
     int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
     int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
-    int n_bwd = 0; int *d_bwd_sn = nullptr, *d_bwd_chunk = nullptr;
+    int n_bwd = 0, bwd_cw = 1; int *d_bwd_sn = nullptr, *d_bwd_chunk = nullptr;
 };
 
 } // namespace
@@ -245,12 +245,15 @@ int upload_factor(admm_hip_ctx *ctx) {
     for (size_t l = 0; l < F.levels.size(); ++l) {
         LevelDev &L = ctx->levels[l];
         std::vector<int> ssn, stile, bsn, btile, wsn, wchunk;
+        int maxk = 0;
+        for (int s : F.levels[l]) maxk = std::max(maxk, F.sn[s].ncols);
+        L.bwd_cw = (maxk <= 64) ? 4 : 1;          // columns per wave in the backward kernel
         for (int s : F.levels[l]) {
             const Supernode &S = F.sn[s];
             const int f = S.ncols + S.nrows;
             const int tiles = (f + 63) / 64;
             for (int t = 0; t < tiles; ++t) { if (S.ncols <= admm_dev::FWD_SMALL_KMAX) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
-            const int chunks = (S.ncols + admm_dev::BWD_COLS - 1) / admm_dev::BWD_COLS;
+            const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
             for (int c = 0; c < chunks; ++c) { wsn.push_back(s); wchunk.push_back(c); }
         }
         L.n_small = (int)ssn.size(); L.n_big = (int)bsn.size(); L.n_bwd = (int)wsn.size();
@@ -431,7 +434,10 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
     for (int l = nl - 1; l >= 0; --l) {
         const LevelDev &L = ctx->levels[l];
-        if (L.n_bwd) hipLaunchKernelGGL(solve_bwd_kernel, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+        if (L.n_bwd) {
+            if (L.bwd_cw == 4) hipLaunchKernelGGL(solve_bwd_kernel<4>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            else hipLaunchKernelGGL(solve_bwd_kernel<1>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+        }
     }
     HIPCHK(hipGetLastError());
     return ADMM_OK;

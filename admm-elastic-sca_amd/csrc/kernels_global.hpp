@@ -239,11 +239,17 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
     }
 }
 
-// Backward sweep: one 256-thread block = (supernode, 4 columns), one wave per
-// column; lanes stride over the rows of the (contiguous) panel column, 4 rows
-// per lane in flight; the vector [w_s ; -x(R_s)] is staged in LDS in row chunks.
-constexpr int BWD_COLS = 4;
+// Backward sweep: one 256-thread block = (supernode, 4*CW columns), each wave owns
+// CW columns; lanes stride over the rows of the (contiguous) panel columns; the
+// vector [w_s ; -x(R_s)] is staged in LDS in row chunks.  CW = 1 for the big
+// supernodes (maximum number of blocks in flight), CW = 4 for levels of small
+// supernodes (one staging of v per 16 columns instead of per 4).
+// (Tried and dropped: walking whole bottom subtrees inside one workgroup with
+// workgroup barriers between levels -- fewer launches but 5-20 % slower, the
+// per-level launches expose more parallelism to hide the dependent index ->
+// slot -> value loads.)
 constexpr int BWD_RCHUNK = 1024;
+template <int CW>
 __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_chunk,
                                                         FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
     __shared__ double vs[BWD_RCHUNK * 3];
@@ -252,11 +258,12 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
     const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
     const int f = k + r;
     const int *rows = F.rows + F.sn_rows_off[s];
-    const int jc0 = chunk * BWD_COLS;           // first column of this block
-    const int j = jc0 + wave;                   // this wave's column
-    const bool col_ok = j < k;
-    const double *Pj = F.panels + F.sn_panel_off[s] + (size_t)f * (col_ok ? j : 0);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int jc0 = chunk * (4 * CW);           // first column of this block
+    const int j0 = jc0 + wave * CW;             // this wave's first column
+    const double *Pj = F.panels + F.sn_panel_off[s] + (size_t)f * min(j0, k - 1);
+    double acc[CW][3];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; }
     // rows < jc0 are never needed by this block (lower triangular diagonal block)
     for (int r0 = jc0; r0 < f; r0 += BWD_RCHUNK) {
         const int rc = min(BWD_RCHUNK, f - r0);
@@ -269,26 +276,42 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
             vs[3 * q] = v0; vs[3 * q + 1] = v1; vs[3 * q + 2] = v2;
         }
         __syncthreads();
-        if (col_ok) {
-            int q = lane;
-            for (; q + 192 < rc; q += 256) {
-                double p[4];
+        if (j0 < k) {
+            if (CW == 1) {
+                int q = lane;
+                for (; q + 192 < rc; q += 256) {
+                    double p[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = r0 + q + 64 * u; p[u] = (i >= j) ? Pj[i] : 0.0; }
+                    for (int u = 0; u < 4; ++u) { const int i = r0 + q + 64 * u; p[u] = (i >= j0) ? Pj[i] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const double *v = &vs[3 * (q + 64 * u)]; a0 += p[u] * v[0]; a1 += p[u] * v[1]; a2 += p[u] * v[2]; }
-            }
-            for (; q < rc; q += 64) {
-                const int i = r0 + q;
-                if (i >= j) { const double p = Pj[i]; const double *v = &vs[3 * q]; a0 += p * v[0]; a1 += p * v[1]; a2 += p * v[2]; }
+                    for (int u = 0; u < 4; ++u) { const double *v = &vs[3 * (q + 64 * u)]; acc[0][0] += p[u] * v[0]; acc[0][1] += p[u] * v[1]; acc[0][2] += p[u] * v[2]; }
+                }
+                for (; q < rc; q += 64) {
+                    const int i = r0 + q;
+                    if (i >= j0) { const double p = Pj[i]; const double *v = &vs[3 * q]; acc[0][0] += p * v[0]; acc[0][1] += p * v[1]; acc[0][2] += p * v[2]; }
+                }
+            } else {
+                for (int q = lane; q < rc; q += 64) {
+                    const int i = r0 + q;
+                    const double *v = &vs[3 * q];
+                    double p[CW];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) p[c] = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) { acc[c][0] += p[c] * v[0]; acc[c][1] += p[c] * v[1]; acc[c][2] += p[c] * v[2]; }
+                }
             }
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
-    if (lane == 0 && col_ok) {
-        double *dst = X + 3 * (size_t)(first + j);
-        dst[0] = a0; dst[1] = a1; dst[2] = a2;
+    for (int c = 0; c < CW; ++c) {
+        double a0 = acc[c][0], a1 = acc[c][1], a2 = acc[c][2];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
+        if (lane == 0 && j0 + c < k) {
+            double *dst = X + 3 * (size_t)(first + j0 + c);
+            dst[0] = a0; dst[1] = a1; dst[2] = a2;
+        }
     }
 }
 
