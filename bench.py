@@ -165,8 +165,17 @@ def main():
     dom = max(cands, key=lambda k: cands[k][1])
     by, sec = cands[dom]
     ach = by / sec / 1e9 if sec > 0 else 0.0
+    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; same workload, 1 GPU).
+    traffic = None
+    try:
+        if (nx, ny, nz) == (32, 32, 163) and world == 1 and dom.startswith("project_tet_kernel"):
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_1M.json")))["kernels"]["admm_dev::project_tet_kernel<0, 5>"]
+            traffic = (pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
+    except Exception:
+        traffic = None
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3,
+            "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3,
             "phases_ms_per_iter": {k: v / iters_total for k, v in phase.items()},
             "all": {k: {"GB/s": (v[0] / v[1] / 1e9 if v[1] > 0 else 0.0), "ms": v[1] * 1e3} for k, v in cands.items()}}
 
