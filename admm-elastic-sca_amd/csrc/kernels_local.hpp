@@ -33,7 +33,7 @@ namespace admm_dev {
 
 constexpr int LOCAL_BLOCK = 256;
 #ifndef ADMM_TET_WAVES
-#define ADMM_TET_WAVES 3   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
+#define ADMM_TET_WAVES 2   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
 #endif
 
 struct BatchDev {
