@@ -19,11 +19,13 @@ from . import meshgen  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libadmm_hip.so")
 
-KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7)
-KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4]
-KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9]
-KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1]
-KIND_STATE = [0, 0, 0, 0, 4, 4, 0, 0]
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1]
+KIND_STATE = [0, 0, 0, 0, 4, 4, 0, 0, 0]
+SHAPE = dict(FLOOR=0, SPHERE=1, CYLINDER=2)
+EXPLICIT = dict(CONST=0, WIND=1)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -88,6 +90,8 @@ def lib():
         L.admm_hip_add_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.admm_hip_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         L.admm_hip_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.admm_hip_add_explicit.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _ip, C.POINTER(C.c_int)]
+        L.admm_hip_set_collision_shapes.argtypes = [C.c_void_p, C.c_int, _ip, _dp]
         L.admm_hip_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.admm_hip_finalize.argtypes = [C.c_void_p]
         L.admm_hip_set_weights.argtypes = [C.c_void_p, C.c_int, _dp]
@@ -178,6 +182,19 @@ class System:
 
     def add_gravity(self, g):
         self._chk(self.L.admm_hip_add_gravity(self.h, float(g[0]), float(g[1]), float(g[2])))
+
+    def add_explicit(self, type_, direction, idx=None):
+        d = np.ascontiguousarray(direction, dtype=np.float64)
+        ix = None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
+        n = 0 if ix is None else (ix.size // 3 if type_ == EXPLICIT["WIND"] else ix.size)
+        w = C.c_int()
+        self._chk(self.L.admm_hip_add_explicit(self.h, type_, _d(d), n, _i(ix), C.byref(w)))
+        return w.value
+
+    def set_collision_shapes(self, types, params):
+        t = np.ascontiguousarray(types, dtype=np.int32)
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4)
+        self._chk(self.L.admm_hip_set_collision_shapes(self.h, t.size, _i(t), _d(p)))
 
     def set_gravity(self, which, g):
         self._chk(self.L.admm_hip_set_gravity(self.h, which, float(g[0]), float(g[1]), float(g[2])))

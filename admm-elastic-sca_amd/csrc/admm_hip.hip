@@ -48,6 +48,13 @@ struct Batch {
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
 };
 
+struct Explicit {
+    int type = 0; double dir[3] = {0, 0, 0};
+    std::vector<int32_t> idx;            // CONST: node ids (empty = all); WIND: [n][3] triangle node ids
+    int n = 0;                            // nodes / triangles
+    int *d_idx = nullptr; double *d_force = nullptr; int64_t *d_ptr = nullptr; int *d_tri_of = nullptr;
+};
+
 struct LevelDev {
     int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
     int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
@@ -70,7 +77,9 @@ struct admm_hip_ctx {
     int n_nodes = 0;
     std::vector<double> x, v, m3;
     std::vector<Batch> batches;
-    admm_dev::Gravity grav{};
+    admm_dev::Gravity grav{};             // fast path: only constant all-node forces
+    std::vector<Explicit> explicits; bool explicit_simple = true;
+    admm_dev::ShapeTable shapes{}; admm_dev::ShapeTable *d_shapes = nullptr;
     SymCSC A;
     Factor F;
     admm_hip_info info{};
@@ -127,7 +136,7 @@ void free_device(admm_hip_ctx *ctx) {
 void element_G(int kind, const double *rest, double G[4][3], int &cols) {
     std::memset(G, 0, sizeof(double) * 12);
     switch (kind) {
-    case ADMM_KIND_ANCHOR: cols = 1; G[0][0] = 1.0; break;
+    case ADMM_KIND_ANCHOR: case ADMM_KIND_COLLISION: cols = 1; G[0][0] = 1.0; break;
     case ADMM_KIND_SPRING: cols = 1; G[0][0] = 1.0; G[1][0] = -1.0; break;
     case ADMM_KIND_TET_LINEAR: case ADMM_KIND_TET_VOLUME: case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK:
         cols = 3; for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) G[c][r] = rest[c + 4 * r]; break;
@@ -138,7 +147,7 @@ void element_G(int kind, const double *rest, double G[4][3], int &cols) {
 }
 
 int idx_stride(int kind) {
-    switch (kind) { case ADMM_KIND_ANCHOR: return 1; case ADMM_KIND_SPRING: return 2; default: return 4; }
+    switch (kind) { case ADMM_KIND_ANCHOR: case ADMM_KIND_COLLISION: return 1; case ADMM_KIND_SPRING: return 2; default: return 4; }
 }
 
 // ---- host part of finalize: rest data, rows, A_s, ordering, factorization ----
@@ -351,6 +360,24 @@ int upload_all(admm_hip_ctx *ctx) {
     TRY(dalloc(ctx, &ctx->d_fslot, 3 * (size_t)std::max<int64_t>(slot, 1)));
     HIPCHK(hipMemset(ctx->d_fslot, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slot, 1)));
     TRY(upload(ctx, &ctx->d_inc_ptr, inc_ptr));
+    // collision shapes and the general explicit forces (index lists in factor order)
+    TRY(dalloc(ctx, &ctx->d_shapes, 1));
+    HIPCHK(hipMemcpy(ctx->d_shapes, &ctx->shapes, sizeof(admm_dev::ShapeTable), hipMemcpyHostToDevice));
+    for (Explicit &E : ctx->explicits) {
+        std::vector<int> pidx(E.idx.size());
+        for (size_t i = 0; i < E.idx.size(); ++i) pidx[i] = F.iperm[E.idx[i]];
+        E.d_idx = nullptr;
+        if (!pidx.empty()) TRY(upload(ctx, &E.d_idx, pidx));
+        if (E.type == ADMM_EXPLICIT_WIND) {
+            TRY(dalloc(ctx, &E.d_force, 3 * (size_t)std::max(E.n, 1)));
+            std::vector<int64_t> ptr(n + 1, 0);
+            for (int t = 0; t < E.n; ++t) for (int c = 0; c < 3; ++c) ptr[pidx[3 * (size_t)t + c] + 1]++;
+            for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+            std::vector<int> tri_of(ptr[n]); std::vector<int64_t> pos(ptr.begin(), ptr.end() - 1);
+            for (int t = 0; t < E.n; ++t) for (int c = 0; c < 3; ++c) tri_of[pos[pidx[3 * (size_t)t + c]]++] = t;   // ascending triangle order per node
+            TRY(upload(ctx, &E.d_ptr, ptr)); TRY(upload(ctx, &E.d_tri_of, tri_of));
+        }
+    }
     HIPCHK(hipDeviceSynchronize());
     ctx->info.t_upload_s = now_s() - t0;
     return ADMM_OK;
@@ -400,6 +427,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
         case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_COLLISION: hipLaunchKernelGGL(project_collision_kernel, grid, block, 0, ctx->stream, d, x, (const ShapeTable *)ctx->d_shapes); break;
         default: return fail(ctx, ADMM_ERR_UNSUPPORTED, "no kernel for kind %d", b.kind);
         }
     }
@@ -542,17 +570,46 @@ int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *
     return ADMM_OK;
 }
 
-int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz) {
-    if (!ctx) return ADMM_ERR_ARG;
-    if (ctx->grav.n >= admm_dev::MAX_GRAV) return fail(ctx, ADMM_ERR_UNSUPPORTED, "at most %d explicit constant forces", admm_dev::MAX_GRAV);
-    double *g = ctx->grav.g[ctx->grav.n++];
-    g[0] = gx; g[1] = gy; g[2] = gz;
+int admm_hip_add_explicit(admm_hip_ctx *ctx, int type, const double *dir, int n_idx, const int32_t *idx, int *which) {
+    if (!ctx || !dir || n_idx < 0 || (n_idx && !idx)) return ADMM_ERR_ARG;
+    if (type != ADMM_EXPLICIT_CONST && type != ADMM_EXPLICIT_WIND) return fail(ctx, ADMM_ERR_UNSUPPORTED, "explicit force type %d", type);
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "explicit forces cannot be added after finalize");
+    Explicit E; E.type = type; E.n = n_idx;
+    for (int j = 0; j < 3; ++j) E.dir[j] = dir[j];
+    E.idx.assign(idx, idx + (size_t)n_idx * (type == ADMM_EXPLICIT_WIND ? 3 : 1));
+    for (int32_t v : E.idx) if (v < 0) return fail(ctx, ADMM_ERR_ARG, "negative node id in explicit force");
+    const bool simple = type == ADMM_EXPLICIT_CONST && n_idx == 0;
+    if (simple && ctx->explicit_simple && ctx->grav.n < admm_dev::MAX_GRAV) { double *g = ctx->grav.g[ctx->grav.n++]; g[0] = dir[0]; g[1] = dir[1]; g[2] = dir[2]; }
+    else ctx->explicit_simple = false;
+    ctx->explicits.push_back(std::move(E));
+    if (which) *which = (int)ctx->explicits.size() - 1;
     return ADMM_OK;
 }
+int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz) {
+    const double d[3] = {gx, gy, gz};
+    return admm_hip_add_explicit(ctx, ADMM_EXPLICIT_CONST, d, 0, nullptr, nullptr);
+}
 int admm_hip_set_gravity(admm_hip_ctx *ctx, int which, double gx, double gy, double gz) {
-    if (!ctx || which < 0 || which >= ctx->grav.n) return ADMM_ERR_ARG;
-    double *g = ctx->grav.g[which];
-    g[0] = gx; g[1] = gy; g[2] = gz;
+    if (!ctx || which < 0 || which >= (int)ctx->explicits.size()) return ADMM_ERR_ARG;
+    double *d = ctx->explicits[which].dir;
+    d[0] = gx; d[1] = gy; d[2] = gz;
+    if (ctx->explicit_simple) { double *g = ctx->grav.g[which]; g[0] = gx; g[1] = gy; g[2] = gz; }
+    return ADMM_OK;
+}
+int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t *types, const double *params) {
+    if (!ctx || n_shapes < 0 || (n_shapes && (!types || !params))) return ADMM_ERR_ARG;
+    if (n_shapes > ADMM_MAX_SHAPES) return fail(ctx, ADMM_ERR_UNSUPPORTED, "at most %d collision shapes", ADMM_MAX_SHAPES);
+    ctx->shapes.n = n_shapes;
+    for (int j = 0; j < n_shapes; ++j) {
+        if (types[j] < ADMM_SHAPE_FLOOR || types[j] > ADMM_SHAPE_CYLINDER) return fail(ctx, ADMM_ERR_UNSUPPORTED, "collision shape type %d", types[j]);
+        ctx->shapes.type[j] = types[j];
+        for (int q = 0; q < 4; ++q) ctx->shapes.par[j][q] = params[4 * (size_t)j + q];
+    }
+    if (ctx->finalized && ctx->device_id >= 0) {
+        HIPCHK(hipSetDevice(ctx->device_id));
+        HIPCHK(hipMemcpyAsync(ctx->d_shapes, &ctx->shapes, sizeof(admm_dev::ShapeTable), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return ADMM_OK;
 }
 
@@ -574,6 +631,7 @@ int admm_hip_finalize(admm_hip_ctx *ctx) {
     if (ctx->dt <= 0.0) { fprintf(stderr, "\n**Solver Error: timestep set to %gs, changing to 0.04s.\n", ctx->dt); ctx->dt = 0.04; }
     if (ctx->n_nodes < 1 || ctx->m3.size() != ctx->x.size()) return fail(ctx, ADMM_ERR_ARG, "**Solver Error: Problem with node data!");
     std::fill(ctx->v.begin(), ctx->v.end(), 0.0); // System.cpp:113
+    for (const Explicit &E : ctx->explicits) for (int32_t v : E.idx) if (v >= ctx->n_nodes) return fail(ctx, ADMM_ERR_ARG, "explicit force references node %d (have %d)", v, ctx->n_nodes);
     TRY(host_assemble(ctx, false));
     TRY(host_factor(ctx, false));
     ctx->info.rank = ctx->rank; ctx->info.world = ctx->world;
@@ -648,7 +706,20 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     // event layout (timing mode): E0 | prologue | E1 | per iter: local E rhs E allreduce E fwd E bwd E | epilogue | E
     ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_pending = ctx->timing;
     TRY(mark(ctx));
-    hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
+    if (ctx->explicit_simple) {
+        hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
+    } else {
+        for (const Explicit &E : ctx->explicits) {      // in list order, like System.cpp:37-39
+            if (E.type == ADMM_EXPLICIT_CONST) {
+                const int cnt = E.idx.empty() ? ctx->n_nodes : E.n;
+                if (cnt) hipLaunchKernelGGL(explicit_const_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, cnt, (const int *)E.d_idx, ctx->dt, E.dir[0], E.dir[1], E.dir[2], ctx->d_v);
+            } else if (E.n) {
+                hipLaunchKernelGGL(wind_force_kernel, dim3((E.n + 255) / 256), dim3(256), 0, ctx->stream, E.n, (const int *)E.d_idx, ctx->dt, E.dir[0], E.dir[1], E.dir[2], ctx->d_x, ctx->d_v, E.d_force);
+                hipLaunchKernelGGL(wind_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, E.d_ptr, E.d_tri_of, E.d_force, ctx->d_v);
+            }
+        }
+        hipLaunchKernelGGL(xbar_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
+    }
     TRY(mark(ctx));
     for (int it = 0; it < admm_iters; ++it) {
         TRY(launch_local(ctx));

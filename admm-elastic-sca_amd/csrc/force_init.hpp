@@ -92,6 +92,9 @@ inline bool force_initialize(int kind, const int *idx, const double *params, con
     case ADMM_KIND_ANCHOR:
         *weight = params[0] > 0.0 ? params[0] : (double)1000.f;
         return true;
+    case ADMM_KIND_COLLISION:   // CollisionForce.hpp:33: weight = use_weight
+        *weight = params[0];
+        return true;
     case ADMM_KIND_SPRING: {
         rest[0] = norm(sub(node(x, idx[0]), node(x, idx[1])));
         *weight = std::sqrt(params[0]);

@@ -34,6 +34,57 @@ __global__ void prologue_kernel(int ndof, double dt, Gravity gr, const double *_
     xcur[i] = xb;
 }
 
+// x_bar = x + dt v ; Mxbar = m x_bar ; x_cur = x_bar (no explicit force folded in)
+__global__ void xbar_kernel(int ndof, double dt, const double *__restrict__ x, const double *__restrict__ v,
+                            const double *__restrict__ m, double *__restrict__ mxbar, double *__restrict__ xcur) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndof) return;
+    const double xb = x[i] + dt * v[i];
+    mxbar[i] = m[i] * xb;
+    xcur[i] = xb;
+}
+
+// ExplicitForce::project, ExplicitForce.cpp:29-39: v += dt*dir on all nodes (idx == NULL) or a subset
+__global__ void explicit_const_kernel(int n, const int *__restrict__ idx, double dt, double gx, double gy, double gz, double *__restrict__ v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int node = idx ? idx[i] : i;
+    v[3 * (size_t)node] += (dt * gx); v[3 * (size_t)node + 1] += (dt * gy); v[3 * (size_t)node + 2] += (dt * gz);
+}
+
+// WindForce::project, ExplicitForce.cpp:42-98, in two deterministic passes: (1) the force of
+// every triangle from the velocity field as it stands, (2) per node, the sum over its
+// incident wind triangles in triangle order.
+__global__ void wind_force_kernel(int n_tris, const int *__restrict__ tris, double dt, double wx, double wy, double wz,
+                                  const double *__restrict__ x, const double *__restrict__ v, double *__restrict__ force) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const size_t i0 = 3 * (size_t)tris[3 * t], i1 = 3 * (size_t)tris[3 * t + 1], i2 = 3 * (size_t)tris[3 * t + 2];
+    const double dir[3] = {wx, wy, wz};
+    double vr[3], a[3], b[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vr[j] = (v[i0 + j] + v[i1 + j] + v[i2 + j]) / 3.0 - dir[j];
+        a[j] = x[i1 + j] - x[i0 + j]; b[j] = x[i2 + j] - x[i0 + j];
+    }
+    const double n0 = a[1] * b[2] - a[2] * b[1], n1 = a[2] * b[0] - a[0] * b[2], n2 = a[0] * b[1] - a[1] * b[0];
+    const double nn = sqrt(n0 * n0 + (n1 * n1 + n2 * n2));
+    const double nm[3] = {n0 / nn, n1 / nn, n2 / nn};
+    const double area = 0.5 * nn;
+    const double v_n = nm[0] * vr[0] + (nm[1] * vr[1] + nm[2] * vr[2]);
+    const double c = -1000.0 * area * v_n * fabs(v_n);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { double f = c * nm[j]; f *= 0.33; f *= dt; force[3 * (size_t)t + j] = f; }
+}
+__global__ void wind_gather_kernel(int n_nodes, const int64_t *__restrict__ ptr, const int *__restrict__ tri_of, const double *__restrict__ force, double *__restrict__ v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_nodes) return;
+    const int node = i / 3, c = i - 3 * node;
+    double vi = v[i];
+    for (int64_t p = ptr[node]; p < ptr[node + 1]; ++p) vi += force[3 * (size_t)tri_of[p] + c];
+    v[i] = vi;
+}
+
 // m_v = (curr_x - m_x) * (1/dt) ; m_x = curr_x             (System.cpp:70-71)
 __global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, double *__restrict__ v, const double *__restrict__ xcur) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

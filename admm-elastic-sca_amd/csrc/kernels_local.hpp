@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "local_math.hpp"
+#include "../../include/admm_kinds.h"
 
 namespace admm_dev {
 
@@ -35,6 +36,8 @@ constexpr int LOCAL_BLOCK = 256;
 #ifndef ADMM_TET_WAVES
 #define ADMM_TET_WAVES 2   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
 #endif
+
+struct ShapeTable { int n; int type[ADMM_MAX_SHAPES]; double par[ADMM_MAX_SHAPES][4]; };
 
 struct BatchDev {
     int n;                 // local elements
@@ -187,6 +190,49 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b,
         const double un = u + (dx - zi);
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
         b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CollisionForce, CollisionForce.cpp:38-70: one element per node, D = I;
+// the point Dx+u is pushed out of every analytic shape it penetrates, in list
+// order (CollisionFloor.hpp:51-58, CollisionSphere.hpp:50-66, CollisionCylinder.hpp:48-66)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) {
+    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int n = b.n;
+    if (e >= n) return;
+    const int id = b.idx[e];
+    const double s = b.w2h2[e];
+    double dx[3], u[3], p[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dx[j] = 0.0 + 1.0 * x[3 * (size_t)id + j];
+        if (b.dx_override) dx[j] = b.dx_override[(size_t)j * n + e];
+        u[j] = b.u[(size_t)j * n + e];
+        p[j] = dx[j] + u[j];
+    }
+    const int ns = shapes->n;
+    for (int q = 0; q < ns; ++q) {
+        const double c0 = shapes->par[q][0], c1 = shapes->par[q][1], c2 = shapes->par[q][2], R = shapes->par[q][3];
+        const int ty = shapes->type[q];
+        if (ty == ADMM_SHAPE_FLOOR) {
+            if (c1 - p[1] > 0) p[1] = c1;
+        } else if (ty == ADMM_SHAPE_SPHERE) {
+            const double d0 = p[0] - c0, d1 = p[1] - c1, d2 = p[2] - c2;
+            const double nrm = sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
+            if (R - nrm > 0) { p[0] = c0 + R * (d0 / nrm); p[1] = c1 + R * (d1 / nrm); p[2] = c2 + R * (d2 / nrm); }
+        } else {
+            const double d0 = p[0] - c0, d1 = p[1] - c1, d2 = 0.0 - 0.0;
+            const double nrm = sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
+            if (R - nrm > 0) { const double pz = p[2]; p[0] = (c0 + R * (d0 / nrm)) + 0.0; p[1] = (c1 + R * (d1 / nrm)) + 0.0; p[2] = (0.0 + R * (d2 / nrm)) + pz; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double un = u[j] + (dx[j] - p[j]);
+        b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = p[j];
+        b.fslot[3 * (size_t)b.dst[e] + j] = s * (p[j] - un);
     }
 }
 

@@ -7,7 +7,7 @@
  * deps/admm-elastic-sca/src/system/System.cpp:26-75 and :98-179) runs behind
  * these entry points, on one GPU per context.  The reference itself has no
  * FFI: its plugin surface is the C++ classes admm::System / admm::Force.  The
- * host-side mirror of those classes (admm-elastic-sca_amd/host/admm/*.hpp)
+ * host-side mirror of those classes (admm-elastic-sca_amd/host/admm/)
  * binds to exactly the functions declared here, and so does the Python
  * plumbing used by bench.py and tests/.  Plain C types only, caller-owned
  * host buffers, int error codes (0 = ok), no exceptions across the boundary.
@@ -76,6 +76,18 @@ int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *
  * (ExplicitForce.hpp:51-59, ExplicitForce.cpp:29-39): v += dt*dir on all nodes,
  * once per frame before the ADMM loop.                                       */
 int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz);
+/* general form: replaces explicit_forces.push_back(new ExplicitForce(dir, indices)) and
+ * new WindForce(tris) (ExplicitForce.hpp:51-71).  type ADMM_EXPLICIT_CONST: idx = node ids
+ * (n_idx = 0: all nodes); ADMM_EXPLICIT_WIND: idx = [n_idx][3] triangle node ids, dir = wind
+ * direction.  Explicit forces are applied in the order they were added.  The reference's
+ * wind loop scatters with an omp critical in thread-dependent order and reads velocities
+ * other threads are updating; here all triangle forces are evaluated on the velocity field
+ * left by the previous explicit force and summed per node in triangle order.            */
+int admm_hip_add_explicit(admm_hip_ctx *ctx, int type, const double *dir, int n_idx, const int32_t *idx, int *which);
+/* replaces: CollisionForce::collisionShapes (CollisionForce.hpp:39): the shape table used by
+ * every ADMM_KIND_COLLISION batch, tested in order like CollisionForce::handleCollisions
+ * (CollisionForce.cpp:55-70).  types [n], params [n][4] (admm_kinds.h).  May be updated between frames. */
+int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t *types, const double *params);
 
 /* ---- multi-GPU ------------------------------------------------------------
  * Elements shard across ranks (contiguous element ranges per batch); nodes and

@@ -16,6 +16,7 @@
  *   TET_STVK      HyperElasticTet type 1       TetForce.cpp:303-364      4    9
  *   TRI_STRAIN    LimitedTriangleStrain        TriangleForce.cpp:29-113  3    6
  *   BEND          BendForce                    BendForce.cpp:26-161      4    9
+ *   COLLISION     CollisionForce (one element per node)  CollisionForce.cpp:27-70  1    3
  *
  * "rows" are the compact rows of D/u/z per element.  (The reference gives
  * every tet 36 rows of which 27 are structurally zero -- TetForce.cpp:61 vs
@@ -37,17 +38,18 @@ enum admm_kind {
     ADMM_KIND_TET_STVK   = 5,
     ADMM_KIND_TRI_STRAIN = 6,
     ADMM_KIND_BEND       = 7,
-    ADMM_KIND_COUNT      = 8
+    ADMM_KIND_COLLISION  = 8,
+    ADMM_KIND_COUNT      = 9
 };
 
 /* nodes per element */
-static const int ADMM_KIND_NODES[ADMM_KIND_COUNT]  = { 1, 2, 4, 4, 4, 4, 3, 4 };
+static const int ADMM_KIND_NODES[ADMM_KIND_COUNT]  = { 1, 2, 4, 4, 4, 4, 3, 4, 1 };
 /* compact D rows per element */
-static const int ADMM_KIND_ROWS[ADMM_KIND_COUNT]   = { 3, 3, 9, 9, 9, 9, 6, 9 };
+static const int ADMM_KIND_ROWS[ADMM_KIND_COUNT]   = { 3, 3, 9, 9, 9, 9, 6, 9, 3 };
 /* doubles of constructor parameters per element (see admm_hip_add_batch) */
-static const int ADMM_KIND_PARAMS[ADMM_KIND_COUNT] = { 2, 1, 1, 3, 3, 3, 4, 1 };
+static const int ADMM_KIND_PARAMS[ADMM_KIND_COUNT] = { 2, 1, 1, 3, 3, 3, 4, 1, 1 };
 /* doubles of persistent warm-start state per element */
-static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0 };
+static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0, 0 };
 
 /*
  * params layout per kind (doubles, element-major [n_elems][ADMM_KIND_PARAMS]):
@@ -59,8 +61,25 @@ static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0 };
  *   TET_NH/STVK { mu, lambda, max_iterations }
  *   TRI_STRAIN  { stiffness, limit_min, limit_max, strain_limiting (1/0) }
  *   BEND        { stiffness }
+ *   COLLISION   { use_weight }   (CollisionForce.hpp:33: default 32); the reference's single
+ *               CollisionForce over all nodes is one batch with one element per node, in node
+ *               order; the shapes are set with admm_hip_set_collision_shapes
  * state layout (TET_NH/STVK): { last_prox_result[3], init_hess }  (TetForce.hpp:146, meta.h:33)
  */
+
+/* analytic collision shapes (deps/admm-elastic-sca/src/collision/), tested in list order */
+enum admm_shape {
+    ADMM_SHAPE_FLOOR    = 0,   /* params { -, cy, -, - }        CollisionFloor.hpp:51-58    */
+    ADMM_SHAPE_SPHERE   = 1,   /* params { cx, cy, cz, radius } CollisionSphere.hpp:50-66   */
+    ADMM_SHAPE_CYLINDER = 2    /* params { cx, cy, -, radius }  z-axis, CollisionCylinder.hpp:48-66 */
+};
+#define ADMM_MAX_SHAPES 64
+
+/* explicit (pre-step) forces, applied to v in list order once per frame (ExplicitForce.cpp) */
+enum admm_explicit {
+    ADMM_EXPLICIT_CONST = 0,   /* v += dt*dir on all nodes, or on an index subset  ExplicitForce.cpp:29-39 */
+    ADMM_EXPLICIT_WIND  = 1    /* per-triangle aerodynamic drag                    ExplicitForce.cpp:42-98 */
+};
 
 #ifdef __cplusplus
 }

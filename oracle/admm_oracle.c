@@ -583,6 +583,9 @@ void orc_force_construct(orc_force *f, int kind, const int *idx, const double *p
     case ADMM_KIND_BEND: /* CORE/BendForce.hpp:32 */
         f->weight = sqrt(params[0]);
         break;
+    case ADMM_KIND_COLLISION: /* CORE/CollisionForce.hpp:33 */
+        f->weight = params[0];
+        break;
     case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK: /* CORE/TetForce.hpp:127-128; OPT/meta.h:33 */
         f->state[0] = f->state[1] = f->state[2] = 1.0; f->state[3] = 1.0;
         break;
@@ -823,9 +826,42 @@ static void project_anchor(orc_force *f, const double *Dx, double *u, double *z)
     for (int i = 0; i < 3; ++i) { u[i] = u[i] + (Dx[i] - zi[i]); z[i] = zi[i]; }
 }
 
+/* CollisionForce::project + handleCollisions, CORE/CollisionForce.cpp:38-70, with the shapes of
+ * deps/admm-elastic-sca/src/collision/CollisionFloor.hpp:51-58, CollisionSphere.hpp:50-66,
+ * CollisionCylinder.hpp:48-66 */
+static int g_n_shapes = 0; static int g_shape_type[ADMM_MAX_SHAPES]; static double g_shape_par[ADMM_MAX_SHAPES][4];
+static void project_collision(orc_force *f, const double *Dx, double *u, double *z) {
+    (void)f;
+    double p[3];
+    for (int i = 0; i < 3; ++i) p[i] = Dx[i] + u[i];
+    for (int j = 0; j < g_n_shapes; ++j) {
+        const double *sp = g_shape_par[j];
+        if (g_shape_type[j] == ADMM_SHAPE_FLOOR) {
+            double err = sp[1] - p[1];
+            if (err > 0) p[1] = sp[1];
+        } else if (g_shape_type[j] == ADMM_SHAPE_SPHERE) {
+            double d[3] = { p[0] - sp[0], p[1] - sp[1], p[2] - sp[2] };
+            double err = sp[3] - norm3f(d);
+            if (err > 0) { double n = norm3f(d); for (int i = 0; i < 3; ++i) p[i] = sp[i] + sp[3] * (d[i] / n); }
+        } else {
+            double c[3] = { sp[0], sp[1], 0.0 };
+            double d[3] = { p[0] - c[0], p[1] - c[1], 0.0 - c[2] };
+            double err = sp[3] - norm3f(d);
+            if (err > 0) { double n = norm3f(d); double add[3] = { 0.0, 0.0, p[2] }; for (int i = 0; i < 3; ++i) p[i] = (c[i] + sp[3] * (d[i] / n)) + add[i]; }
+        }
+    }
+    for (int i = 0; i < 3; ++i) { u[i] = u[i] + (Dx[i] - p[i]); z[i] = p[i]; }
+}
+void orc_set_collision_shapes(orc_system *s, int n, const int *types, const double *params) {
+    (void)s;
+    g_n_shapes = n > ADMM_MAX_SHAPES ? ADMM_MAX_SHAPES : n;
+    for (int j = 0; j < g_n_shapes; ++j) { g_shape_type[j] = types[j]; for (int q = 0; q < 4; ++q) g_shape_par[j][q] = params[4 * j + q]; }
+}
+
 void orc_force_project(orc_force *f, double dt, const double *Dx, double *u, double *z) {
     (void)dt;
     switch (f->kind) {
+    case ADMM_KIND_COLLISION: project_collision(f, Dx, u, z); break;
     case ADMM_KIND_ANCHOR: project_anchor(f, Dx, u, z); break;
     case ADMM_KIND_SPRING: project_spring(f, Dx, u, z); break;
     case ADMM_KIND_TET_LINEAR: case ADMM_KIND_TET_VOLUME: project_tet_blend(f, Dx, u, z); break;
@@ -846,6 +882,7 @@ struct orc_system {
     double *x, *v, *m;
     orc_force *forces; int n_forces, cap_forces;
     double grav[8][3]; int n_grav;
+    int ex_type[8]; int *ex_idx[8]; int ex_n[8];
     /* assembled */
     trip *T; long nT, capT;
     double *W; int nW, capW;
@@ -908,7 +945,41 @@ void orc_set_control_point(orc_system *s, int fi, const double *pos, int active)
     f->active = active;
 }
 void orc_add_gravity(orc_system *s, double gx, double gy, double gz) {
-    if (s->n_grav < 8) { s->grav[s->n_grav][0] = gx; s->grav[s->n_grav][1] = gy; s->grav[s->n_grav][2] = gz; s->n_grav++; }
+    if (s->n_grav < 8) { s->grav[s->n_grav][0] = gx; s->grav[s->n_grav][1] = gy; s->grav[s->n_grav][2] = gz; s->ex_type[s->n_grav] = ADMM_EXPLICIT_CONST; s->ex_idx[s->n_grav] = NULL; s->ex_n[s->n_grav] = 0; s->n_grav++; }
+}
+void orc_add_explicit(orc_system *s, int type, const double *dir, int n_idx, const int *idx) {
+    if (s->n_grav >= 8) return;
+    const int k = s->n_grav++;
+    for (int j = 0; j < 3; ++j) s->grav[k][j] = dir[j];
+    s->ex_type[k] = type; s->ex_n[k] = n_idx;
+    const int cnt = (type == ADMM_EXPLICIT_WIND ? 3 : 1) * n_idx;
+    s->ex_idx[k] = cnt ? (int *)malloc(sizeof(int) * cnt) : NULL;
+    for (int i = 0; i < cnt; ++i) s->ex_idx[k][i] = idx[i];
+}
+void orc_set_explicit_dir(orc_system *s, int which, const double *dir) { for (int j = 0; j < 3; ++j) s->grav[which][j] = dir[j]; }
+
+/* WindForce::project, CORE/ExplicitForce.cpp:42-98, serial triangle order */
+static void wind_project(const orc_system *s, int k, double dt) {
+    const double *dirv = s->grav[k];
+    double *v = s->v; const double *x = s->x;
+    for (int t = 0; t < s->ex_n[k]; ++t) {
+        int id[3] = { s->ex_idx[k][3 * t] * 3, s->ex_idx[k][3 * t + 1] * 3, s->ex_idx[k][3 * t + 2] * 3 };
+        double cv[3], vr[3];
+        for (int j = 0; j < 3; ++j) { cv[j] = (v[id[0] + j] + v[id[1] + j] + v[id[2] + j]) / 3.0; vr[j] = cv[j] - dirv[j]; }
+        double a[3], b[3], n[3];
+        for (int j = 0; j < 3; ++j) { a[j] = x[id[1] + j] - x[id[0] + j]; b[j] = x[id[2] + j] - x[id[0] + j]; }
+        cross3(a, b, n);
+        double nn = norm3f(n);
+        double normal[3] = { n[0] / nn, n[1] / nn, n[2] / nn };
+        double area = 0.5 * norm3f(n);
+        double v_n = dot3f(normal, vr);
+        double c = -1000.0 * area * v_n * fabs(v_n);
+        for (int j = 0; j < 3; ++j) {
+            double force = c * normal[j];
+            force *= 0.33; force *= dt;
+            v[id[0] + j] += force; v[id[1] + j] += force; v[id[2] + j] += force;
+        }
+    }
 }
 
 static void push_trip(orc_system *s, int r, int c, double v) {
@@ -929,6 +1000,9 @@ static void get_selector(orc_system *s, orc_force *f) {
     switch (f->kind) {
     case ADMM_KIND_ANCHOR: /* CORE/AnchorForce.cpp:37-44,61-68 */
         for (int i = 0; i < 3; ++i) { push_w(s, f->weight); push_trip(s, g + i, 3 * f->idx[0] + i, 1.0); }
+        break;
+    case ADMM_KIND_COLLISION: /* CORE/CollisionForce.cpp:27-35 (one element per node) */
+        for (int i = 0; i < 3; ++i) { push_trip(s, g + i, 3 * f->idx[0] + i, 1.0); push_w(s, f->weight); }
         break;
     case ADMM_KIND_SPRING: /* CORE/Force.cpp:40-50 */
         for (int i = 0; i < 3; ++i) { push_trip(s, i + g, 3 * f->idx[0] + i, 1.0); push_trip(s, i + g, 3 * f->idx[1] + i, -1.0); }
@@ -1088,7 +1162,11 @@ static void spmv_D(const orc_system *s, const double *x, double *y) {
 int orc_step(orc_system *s) {
     const int n = s->dof, R = s->nW; const double dt = s->dt;
     /* ExplicitForce::project, CORE/ExplicitForce.cpp:29-39 */
-    for (int gI = 0; gI < s->n_grav; ++gI) for (int i = 0; i < n / 3; ++i) for (int j = 0; j < 3; ++j) s->v[3 * i + j] += (dt * s->grav[gI][j]);
+    for (int gI = 0; gI < s->n_grav; ++gI) {
+        if (s->ex_type[gI] == ADMM_EXPLICIT_WIND) { wind_project(s, gI, dt); continue; }
+        if (s->ex_n[gI] == 0) { for (int i = 0; i < n / 3; ++i) for (int j = 0; j < 3; ++j) s->v[3 * i + j] += (dt * s->grav[gI][j]); }
+        else for (int q = 0; q < s->ex_n[gI]; ++q) for (int j = 0; j < 3; ++j) s->v[3 * s->ex_idx[gI][q] + j] += (dt * s->grav[gI][j]);
+    }
     spmv_D(s, s->x, s->z);                                  /* curr_z = D*m_x          :43 */
     double *M_xbar = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; ++i) { double xb = s->x[i] + dt * s->v[i]; M_xbar[i] = s->m[i] * xb; s->xc[i] = xb; } /* :46-48 */

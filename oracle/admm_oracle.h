@@ -2,7 +2,7 @@
  * admm_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
  *
  * A plain-C restatement of the reference's ADMM hot path
- * (mattoverby/admm-elastic-sca, deps/admm-elastic-sca/src/system/*, the
+ * (mattoverby/admm-elastic-sca, deps/admm-elastic-sca/src/system/, the
  * vendored cppoptlib L-BFGS / More-Thuente and Eigen 3.2.5 JacobiSVD),
  * function by function, each citing the reference file:line it follows.
  *
@@ -70,6 +70,13 @@ int  orc_add_forces(orc_system *s, int kind, int n, const int *idx, const double
 int  orc_add_moving_anchor(orc_system *s, int idx, const double *pos, int active, double use_weight);
 void orc_set_control_point(orc_system *s, int force_index, const double *pos, int active);
 void orc_add_gravity(orc_system *s, double gx, double gy, double gz);
+/* ExplicitForce with an index subset / WindForce over triangles (ExplicitForce.cpp:29-98).
+ * Wind is evaluated in the reference's SERIAL order (triangle i sees the velocity updates of
+ * triangles < i), i.e. what the reference computes with OMP_NUM_THREADS=1. */
+void orc_add_explicit(orc_system *s, int type, const double *dir, int n_idx, const int *idx);
+void orc_set_explicit_dir(orc_system *s, int which, const double *dir);
+/* CollisionForce's shape table (CollisionForce.cpp:55-70) */
+void orc_set_collision_shapes(orc_system *s, int n, const int *types, const double *params);
 int  orc_initialize(orc_system *s);
 int  orc_step(orc_system *s);
 int  orc_dof(orc_system *s);

@@ -22,6 +22,10 @@
 #include "TriangleForce.hpp"
 #include "BendForce.hpp"
 #include "ExplicitForce.hpp"
+#include "CollisionForce.hpp"
+#include "CollisionFloor.hpp"
+#include "CollisionSphere.hpp"
+#include "CollisionCylinder.hpp"
 #include <Eigen/SVD>
 #include <chrono>
 #include <cstring>
@@ -123,6 +127,29 @@ void ref_add_wind(void *h, int n_tris, const int *tris, double dx, double dy, do
     std::shared_ptr<WindForce> w(new WindForce(t));
     w->direction = Eigen::Vector3d(dx, dy, dz);
     s->explicit_forces.push_back(w);
+}
+
+// ExplicitForce on an index subset (ExplicitForce.hpp:56)
+void ref_add_explicit_subset(void *h, int n, const int *idx, double gx, double gy, double gz) {
+    RefSystem *s = (RefSystem *)h;
+    std::vector<int> id(idx, idx + n);
+    s->explicit_forces.push_back(std::shared_ptr<ExplicitForce>(new ExplicitForce(Eigen::Vector3d(gx, gy, gz), id)));
+}
+void ref_set_explicit_dir(void *h, int which, double gx, double gy, double gz) {
+    ((RefSystem *)h)->explicit_forces[which]->direction = Eigen::Vector3d(gx, gy, gz);
+}
+// CollisionForce over all nodes with analytic shapes (CollisionForce.hpp:33; plinkopony.cpp:53-96)
+int ref_add_collision(void *h, int n_shapes, const int *types, const double *params, double use_weight) {
+    RefSystem *s = (RefSystem *)h;
+    std::vector<std::shared_ptr<CollisionShape> > shapes;
+    for (int j = 0; j < n_shapes; ++j) {
+        const double *p = params + 4 * j;
+        if (types[j] == ADMM_SHAPE_FLOOR) shapes.push_back(std::shared_ptr<CollisionShape>(new CollisionFloor(Eigen::Vector3d(p[0], p[1], p[2]))));
+        else if (types[j] == ADMM_SHAPE_SPHERE) shapes.push_back(std::shared_ptr<CollisionShape>(new CollisionSphere(Eigen::Vector3d(p[0], p[1], p[2]), p[3])));
+        else shapes.push_back(std::shared_ptr<CollisionShape>(new CollisionCylinder(Eigen::Vector3d(p[0], p[1], p[2]), Eigen::Vector3d(1, 1, 1), p[3])));
+    }
+    s->forces.push_back(std::shared_ptr<Force>(new CollisionForce(shapes, use_weight)));
+    return (int)s->forces.size();
 }
 
 int ref_initialize(void *h) { return ((RefSystem *)h)->initialize() ? 1 : 0; }

@@ -15,10 +15,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7)
-KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4]
-KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9]
-KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1]
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1]
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -131,6 +131,11 @@ class Ref(_Sys):
             lib.ref_add_moving_anchor.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, C.c_double]
             lib.ref_set_force_weight.argtypes = [C.c_void_p, C.c_int, C.c_double]
             lib.ref_add_wind.argtypes = [C.c_void_p, C.c_int, ip, C.c_double, C.c_double, C.c_double]
+            lib.ref_add_explicit_subset.argtypes = [C.c_void_p, C.c_int, ip, C.c_double, C.c_double, C.c_double]
+            lib.ref_add_explicit_subset.restype = None
+            lib.ref_set_explicit_dir.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+            lib.ref_set_explicit_dir.restype = None
+            lib.ref_add_collision.argtypes = [C.c_void_p, C.c_int, ip, dp, C.c_double]
             lib.ref_project_single.argtypes = [C.c_int, dp, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp, ip, dp]
             for n in ("add_nodes", "add_forces", "set_control_point", "initialize", "step", "dof", "rows", "n_forces",
                       "get_x", "set_x", "get_v", "set_v", "get_u", "get_z", "get_wdiag", "force_global_idx", "force_weight",
@@ -203,6 +208,17 @@ class Ref(_Sys):
     def add_wind(self, tris, direction):
         tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
         self.lib.ref_add_wind(self.h, tris.shape[0], _i(tris), *[float(d) for d in direction])
+
+    def add_explicit_subset(self, idx, g):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.lib.ref_add_explicit_subset(self.h, idx.size, _i(idx), float(g[0]), float(g[1]), float(g[2]))
+
+    def set_explicit_dir(self, which, g):
+        self.lib.ref_set_explicit_dir(self.h, which, float(g[0]), float(g[1]), float(g[2]))
+
+    def add_collision(self, types, params, weight=32.0):
+        t = np.ascontiguousarray(types, dtype=np.int32); p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4)
+        return self.lib.ref_add_collision(self.h, t.size, _i(t), _d(p), float(weight))
 
     def recompute_weights(self):
         self.lib.ref_recompute_weights(self.h)
@@ -278,7 +294,9 @@ class Oracle(_Sys):
             lib.orc_force_construct.argtypes = [C.POINTER(OrcForce), C.c_int, ip, dp]
             lib.orc_force_initialize.argtypes = [C.POINTER(OrcForce), dp]
             lib.orc_force_project.argtypes = [C.POINTER(OrcForce), C.c_double, dp, dp, dp]
-            for n in ("settings", "set_layout", "add_gravity", "destroy", "get_D", "set_control_point", "svd3", "svd32",
+            lib.orc_add_explicit.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, ip]
+            lib.orc_set_collision_shapes.argtypes = [C.c_void_p, C.c_int, ip, dp]
+            for n in ("settings", "set_layout", "add_gravity", "destroy", "get_D", "set_control_point", "svd3", "svd32", "add_explicit", "set_collision_shapes",
                       "oriented_svd", "force_construct", "force_initialize", "force_project"):
                 getattr(lib, "orc_" + n).restype = None
             cls.lib = lib
@@ -325,6 +343,16 @@ class Oracle(_Sys):
     @property
     def wdiag(self):
         return self._view("wdiag", self.rows).copy()
+
+    def add_explicit(self, type_, direction, idx=None):
+        d = np.ascontiguousarray(direction, dtype=np.float64)
+        ix = np.zeros(0, np.int32) if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
+        n = ix.size // 3 if type_ == 1 else ix.size
+        self.lib.orc_add_explicit(self.h, type_, _d(d), n, _i(ix))
+
+    def set_collision_shapes(self, types, params):
+        t = np.ascontiguousarray(types, dtype=np.int32); p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4)
+        self.lib.orc_set_collision_shapes(self.h, t.size, _i(t), _d(p))
 
     def force(self, i):
         return self.lib.orc_get_force(self.h, i).contents

@@ -20,6 +20,7 @@ Fixtures
   traj_bunny_stvk.npz  bunnyexpand mesh (2510 StVK tets), x scaled x1.3 after initialize, 2 frames (chaotic afterwards: 1-ulp sensitivity > 1e-3)
   traj_cloth.npz       30x20 sym-plane cloth, TriangleStrain + Bend + 2 anchors, 3 frames x 30 iters
   assembly_bar.npz     global_idx, W diagonal and D triplets in the reference's own row layout
+  traj_collision.npz   plinkopony-like: corotational tets falling on cylinders / sphere / floor (CollisionForce)
 """
 import os
 import sys
@@ -259,7 +260,38 @@ def make_cloth():
     print("cloth: nodes", n, "tris", tris.shape[0], "hinges", hinges.shape[0])
 
 
+def make_collision():
+    """plinkopony-like (samples/plinkopony/plinkopony.cpp:53-96): a LinearTetStrain body falls on
+    z-axis cylinders, a sphere and a floor; one CollisionForce over all nodes, weight 32."""
+    dims = (3, 3, 5)
+    x, t = meshgen.bar(*dims, h=0.1)
+    x = x + np.array([0.0, 1.0, 0.0])
+    m = meshgen.lumped_tet_mass(x, t, 100.0)
+    types = np.array([2, 2, 1, 0], dtype=np.int32)
+    params = np.array([[0.05, 0.6, 0, 0.12], [0.35, 0.45, 0, 0.1], [0.15, 0.2, 0.25, 0.15], [0, -0.2, 0, 0]], dtype=np.float64)
+
+    def build():
+        r = Ref(); r.settings(0.02, 15)
+        r.add_nodes(x.ravel(), np.repeat(m, 3))
+        r.add_forces(KIND["TET_LINEAR"], t, [1000.0])
+        r.add_collision(types, params, 32.0)
+        r.add_gravity([0, -9.8, 0])
+        assert r.initialize()
+        return r
+    r = build()
+    X = []
+    for _ in range(40):
+        r.step(); X.append(r.x.copy())
+    X = np.array(X)
+    keep = [0, 4, 9, 19, 29, 39]
+    env = envelope(build, 40)
+    np.savez_compressed(os.path.join(HERE, "traj_collision.npz"), x=x, tets=t, mass=m, types=types, params=params, weight=32.0, k=1000.0, dt=0.02, iters=15,
+                        frames=np.array(keep), x_frames=X[keep], ulp_sensitivity=env[keep], global_idx=r.global_idx(), wdiag_tail=r.wdiag[-6:])
+    print("collision: min y", X[-1].reshape(-1, 3)[:, 1].min(), "envelope", env[keep])
+
+
 if __name__ == "__main__":
+    make_collision()
     make_projects()
     make_known_answers()
     make_bars()

@@ -376,3 +376,85 @@ def test_full_size_properties(pkg):
     s.write_local(1, u=np.zeros((33 * 33, 3)))
     s.step(20); xb = s.m_x
     assert np.array_equal(xa, xb)
+
+
+def test_collision_fixture(pkg):
+    """plinkopony-like scene against the compiled reference's trajectory (continuous algorithm: tight)."""
+    g = golden("traj_collision.npz")
+    n = g["x"].shape[0]
+    s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
+    s.add_nodes(g["x"].ravel(), np.repeat(g["mass"], 3))
+    s.add_forces(KIND["TET_LINEAR"], g["tets"], [float(g["k"])])
+    b = s.add_forces(KIND["COLLISION"], np.arange(n), [float(g["weight"])])
+    s.set_collision_shapes(g["types"], g["params"])
+    s.add_gravity([0, -9.8, 0])
+    s.initialize()
+    fi = 0
+    for f in range(int(g["frames"][-1]) + 1):
+        s.step(int(g["iters"]))
+        if f == g["frames"][fi]:
+            assert np.abs(s.m_x - g["x_frames"][fi]).max() < max(tol(g, fi), 1e-9), f
+            fi += 1
+    # the collision projection itself, bit-exact against the oracle on random points
+    rng = np.random.default_rng(3)
+    o = Oracle(); o.settings(0.02, 1)
+    o.add_nodes(g["x"].ravel(), np.repeat(g["mass"], 3))
+    o.add_forces(KIND["COLLISION"], np.arange(n), [32.0]); o.set_collision_shapes(g["types"], g["params"])
+    assert o.initialize()
+    s2 = pkg.System(device_id=0); s2.set_timestep(0.02)
+    s2.add_nodes(g["x"].ravel(), np.repeat(g["mass"], 3))
+    s2.add_forces(KIND["COLLISION"], np.arange(n), [32.0]); s2.set_collision_shapes(g["types"], g["params"])
+    s2.initialize()
+    for it in range(3):
+        xc = rng.uniform(-0.4, 0.9, size=3 * n)
+        s2.local_step_only(xc)
+        u, z = oracle_local_step(o, xc, n, 3)
+        out = s2.read_local(0)
+        assert np.array_equal(out["z"], z) and np.array_equal(out["u"], u)
+
+
+def test_explicit_forces(pkg):
+    """ExplicitForce on an index subset (bit-exact frame) and WindForce (two-pass form) on a cloth."""
+    mg = pkg.meshgen
+    x, tris = mg.sym_plane(6, 4, size=1.0)
+    hinges = mg.bend_hinges(tris)
+    n = x.shape[0]
+    sub = np.arange(1, n, 2, dtype=np.int32)
+
+    def build(S):
+        s = S
+        s.add_nodes(x.ravel(), np.full(3 * n, 0.5 / n))
+        s.add_forces(KIND["TRI_STRAIN"], tris, [100.0, 0.95, 1.05, 1.0])
+        s.add_forces(KIND["BEND"], hinges, [20.0])
+        s.add_forces(KIND["ANCHOR"], [0, 6], [-1.0, 1.0])
+        s.add_gravity([0, -9.8, 0])
+        return s
+    s = build(pkg.System(device_id=0)); s.set_timestep(0.04)
+    o = build(Oracle()); o.settings(0.04, 10)
+    s.add_explicit(pkg.EXPLICIT["CONST"], [0.5, 0.0, 0.2], sub); o.add_explicit(0, [0.5, 0.0, 0.2], sub)
+    s.initialize(); assert o.initialize()
+    for f in range(4):
+        s.step(10); o.step()
+        assert np.abs(s.m_x - o.x).max() < 1e-9
+    # wind: one frame from rest has v = dt*g on every node before the wind -> the serial and the
+    # two-pass evaluation differ only by the in-flight increments; compare against a numpy two-pass
+    s = build(pkg.System(device_id=0)); s.set_timestep(0.04)
+    w = s.add_explicit(pkg.EXPLICIT["WIND"], [10.0, 0.0, 2.0], tris)
+    s.initialize()
+    s.step(0)                                    # explicit forces only (admm_iters = 0): x += dt v
+    v = s.m_v.reshape(-1, 3)
+    v0 = np.tile(0.04 * np.array([0, -9.8, 0]), (n, 1))
+    X = x
+    a = X[tris[:, 1]] - X[tris[:, 0]]; b = X[tris[:, 2]] - X[tris[:, 0]]
+    nrm = np.cross(a, b); nn = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nh = nrm / nn; area = 0.5 * nn[:, 0]
+    vr = (v0[tris[:, 0]] + v0[tris[:, 1]] + v0[tris[:, 2]]) / 3.0 - np.array([10.0, 0, 2.0])
+    vn = (nh * vr).sum(1)
+    force = (-1000.0 * area * vn * np.abs(vn))[:, None] * nh * 0.33 * 0.04
+    vexp = v0.copy()
+    for c in range(3):
+        np.add.at(vexp, tris[:, c], force)
+    assert np.abs(v - vexp).max() < 1e-12 * max(1.0, np.abs(vexp).max())
+    s.set_gravity(w, [0.0, 0.0, 0.0])            # direction is host-mutable (windyflag.cpp:141-152)
+    s.step(5)
+    assert np.isfinite(s.m_x).all()

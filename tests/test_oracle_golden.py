@@ -149,3 +149,23 @@ def test_cloth_trajectory():
     for f in range(g["x_frames"].shape[0]):
         o.step()
         assert np.abs(o.x - g["x_frames"][f]).max() < tol(g, f)
+
+
+def test_collision_trajectory():
+    g = golden("traj_collision.npz")
+    n = g["x"].shape[0]
+    o = Oracle(); o.settings(float(g["dt"]), int(g["iters"]))
+    o.add_nodes(g["x"].ravel(), np.repeat(g["mass"], 3))
+    o.add_forces(KIND["TET_LINEAR"], g["tets"], [float(g["k"])])
+    o.add_forces(KIND["COLLISION"], np.arange(n), [float(g["weight"])])
+    o.set_collision_shapes(g["types"], g["params"])
+    o.add_gravity([0, -9.8, 0])
+    assert o.initialize()
+    nt = g["tets"].shape[0]
+    assert np.array_equal(o.global_idx()[:nt] * 4, g["global_idx"][:nt])     # compact rows = reference rows / 4 for tets
+    fi = 0
+    for f in range(int(g["frames"][-1]) + 1):
+        o.step()
+        if f == g["frames"][fi]:
+            assert np.abs(o.x - g["x_frames"][fi]).max() < tol(g, fi), f
+            fi += 1
