@@ -149,16 +149,65 @@ static inline Vector3d linear_move(double total_elapsed_dt, double start_dt, dou
 }
 } // namespace helper
 
-// ExplicitForce.hpp:51-59: constant acceleration on all nodes (gravity).  A
-// non-empty index list has no device path yet: System::initialize() refuses it.
+// deps/admm-elastic-sca/src/collision/: analytic shapes tested in list order by CollisionForce
+class CollisionShape {
+public:
+    CollisionShape(Vector3d shapeCenter) { center = shapeCenter; }
+    virtual ~CollisionShape() {}
+    virtual int shape_type() const = 0;                 // ADMM_SHAPE_*
+    virtual double shape_radius() const { return 0.0; }
+    Vector3d center;
+};
+class CollisionFloor : public CollisionShape {
+public:
+    CollisionFloor(Vector3d shapeCenter) : CollisionShape(shapeCenter), radius(0) {}
+    int shape_type() const { return ADMM_SHAPE_FLOOR; }
+    double radius;
+};
+class CollisionSphere : public CollisionShape {
+public:
+    CollisionSphere(Vector3d shapeCenter, double sphRadius) : CollisionShape(shapeCenter), radius(sphRadius) {}
+    int shape_type() const { return ADMM_SHAPE_SPHERE; }
+    double shape_radius() const { return radius; }
+    double radius;
+};
+// axis parallel to z through (center.x, center.y); CollisionCylinder.hpp:48-50 drops center.z
+class CollisionCylinder : public CollisionShape {
+public:
+    CollisionCylinder(Vector3d shapeCenter, Vector3d /*cylScale*/, double cylRadius) : CollisionShape(Vector3d(shapeCenter[0], shapeCenter[1], 0)), radius(cylRadius), length(0) {}
+    int shape_type() const { return ADMM_SHAPE_CYLINDER; }
+    double shape_radius() const { return radius; }
+    double radius, length;
+};
+
+// One force over ALL nodes (CollisionForce.hpp:31-46): a batch with one element per node.
+class CollisionForce : public Force {
+public:
+    CollisionForce(std::vector<std::shared_ptr<CollisionShape> > &collShapes, double use_weight = 32.0) : collisionShapes(collShapes), Di_rows(0), n_nodes(0) { weight = use_weight; }
+    int kind() const { return ADMM_KIND_COLLISION; }
+    std::vector<std::shared_ptr<CollisionShape> > collisionShapes;
+    int Di_rows, n_nodes;
+};
+
+// ExplicitForce.hpp:51-59: constant acceleration on all nodes or on an index subset
 class ExplicitForce {
 public:
     ExplicitForce(std::vector<int> indices_ = std::vector<int>(0)) { indices = indices_; }
     ExplicitForce(Vector3d direction_, std::vector<int> indices_ = std::vector<int>(0)) { direction = direction_; indices = indices_; }
     virtual ~ExplicitForce() {}
-    virtual bool is_constant() const { return indices.empty(); }
+    virtual int explicit_type() const { return ADMM_EXPLICIT_CONST; }
+    virtual const std::vector<int> &index_list() const { return indices; }
     Vector3d direction;
     std::vector<int> indices;
+};
+
+// ExplicitForce.hpp:62-71: aerodynamic drag on a list of triangles; direction is host-mutable
+class WindForce : public ExplicitForce {
+public:
+    WindForce(std::vector<int> &tris_) : tris(tris_) { this->direction = Vector3d(0, 0, 0); }
+    int explicit_type() const { return ADMM_EXPLICIT_WIND; }
+    const std::vector<int> &index_list() const { return tris; }
+    std::vector<int> tris;
 };
 
 } // namespace admm

@@ -85,6 +85,19 @@ public:
         for (size_t i = 0; i < forces.size();) {
             const int kind = forces[i]->kind();
             if (kind < 0) { std::cerr << "\n**Solver Error: force " << i << " is a user-defined Force subclass; only the built-in kinds have GPU kernels" << std::endl; return false; }
+            if (kind == ADMM_KIND_COLLISION) {           // one force over all nodes -> one element per node
+                CollisionForce *cf = static_cast<CollisionForce *>(forces[i].get());
+                const int nn_ = dof / 3;
+                std::vector<int32_t> idx(nn_); std::vector<double> par(nn_, cf->weight);
+                for (int q = 0; q < nn_; ++q) idx[q] = q;
+                int b = -1;
+                if (!check(admm_hip_add_batch(gpu, kind, nn_, idx.data(), par.data(), nullptr, &b))) return false;
+                cf->n_nodes = nn_; cf->Di_rows = dof;
+                if (!push_shapes(cf)) return false;
+                batch_first.push_back((int)i); batch_count.push_back(1); batch_kind.push_back(kind); batch_moving.push_back(false);
+                ++i;
+                continue;
+            }
             const bool moving = dynamic_cast<MovingAnchor *>(forces[i].get()) != nullptr;
             size_t j = i;
             std::vector<int32_t> idx; std::vector<double> par, tgt;
@@ -101,15 +114,26 @@ public:
             i = j;
         }
         for (size_t i = 0; i < explicit_forces.size(); ++i) {
-            if (!explicit_forces[i]->is_constant()) { std::cerr << "\n**Solver Error: explicit force " << i << " is not a constant acceleration on all nodes (no device path yet)" << std::endl; return false; }
-            const Vector3d &d = explicit_forces[i]->direction;
-            if (!check(admm_hip_add_gravity(gpu, d[0], d[1], d[2]))) return false;
+            const ExplicitForce &ef = *explicit_forces[i];
+            const double d[3] = {ef.direction[0], ef.direction[1], ef.direction[2]};
+            const std::vector<int> &il = ef.index_list();
+            const int type = ef.explicit_type();
+            const int cnt = (int)il.size() / (type == ADMM_EXPLICIT_WIND ? 3 : 1);
+            std::vector<int32_t> il32(il.begin(), il.end());
+            if (!check(admm_hip_add_explicit(gpu, type, d, cnt, il32.empty() ? nullptr : il32.data(), nullptr))) return false;
         }
         if (!check(admm_hip_finalize(gpu))) return false;
         // write back what Force::initialize / get_selector compute in the reference
         for (size_t b = 0; b < batch_first.size(); ++b) {
-            std::vector<double> w(batch_count[b]), rest((size_t)batch_count[b] * 12); std::vector<int32_t> g(batch_count[b]);
+            const int ne = batch_kind[b] == ADMM_KIND_COLLISION ? dof / 3 : batch_count[b];
+            std::vector<double> w(ne), rest((size_t)ne * 12); std::vector<int32_t> g(ne);
+            if (batch_kind[b] == ADMM_KIND_COLLISION) {
+                if (!check(admm_hip_read_rest(gpu, (int)b, w.data(), rest.data(), g.data()))) return false;
+                forces[batch_first[b]]->global_idx = g[0];
+                continue;
+            }
             if (!check(admm_hip_read_rest(gpu, (int)b, w.data(), rest.data(), g.data()))) return false;
+            if (batch_kind[b] == ADMM_KIND_COLLISION) continue;   // weight stays use_weight; rows start at the batch's first element
             for (int e = 0; e < batch_count[b]; ++e) { Force *f = forces[batch_first[b] + e].get(); f->weight = w[e]; f->global_idx = g[e]; }
         }
         if (settings.verbose >= 1) std::cout << m_x.size() / 3 << " nodes, " << forces.size() << " forces" << std::endl;
@@ -132,6 +156,7 @@ public:
             if (!check(admm_hip_update_anchors(gpu, (int)b, tgt.data(), act.data()))) return false;
         }
         for (size_t i = 0; i < explicit_forces.size(); ++i) { const Vector3d &d = explicit_forces[i]->direction; if (!check(admm_hip_set_gravity(gpu, (int)i, d[0], d[1], d[2]))) return false; }
+        for (size_t b = 0; b < batch_first.size(); ++b) if (batch_kind[b] == ADMM_KIND_COLLISION && !push_shapes(static_cast<CollisionForce *>(forces[batch_first[b]].get()))) return false;
         // m_x / m_v are public and may have been edited by the caller between steps
         if (!check(admm_hip_set_x(gpu, m_x.data())) || !check(admm_hip_set_v(gpu, m_v.data()))) return false;
         if (!check(admm_hip_step(gpu, settings.admm_iters))) return false;
@@ -153,8 +178,9 @@ public:
     void recompute_weights() {
         if (!initialized) return;
         for (size_t b = 0; b < batch_first.size(); ++b) {
-            std::vector<double> w(batch_count[b]);
-            for (int e = 0; e < batch_count[b]; ++e) w[e] = forces[batch_first[b] + e]->weight;
+            const int ne = batch_kind[b] == ADMM_KIND_COLLISION ? (int)m_x.size() / 3 : batch_count[b];
+            std::vector<double> w(ne);
+            for (int e = 0; e < ne; ++e) w[e] = forces[batch_first[b] + (batch_kind[b] == ADMM_KIND_COLLISION ? 0 : e)]->weight;
             if (!check(admm_hip_set_weights(gpu, (int)b, w.data()))) return;
         }
         check(admm_hip_recompute_weights(gpu));
@@ -167,6 +193,16 @@ protected:
     admm_hip_ctx *gpu;
     std::vector<int> batch_first, batch_count, batch_kind;
     std::vector<char> batch_moving;
+
+    bool push_shapes(const CollisionForce *cf) {
+        std::vector<int32_t> ty; std::vector<double> par;
+        for (size_t q = 0; q < cf->collisionShapes.size(); ++q) {
+            const CollisionShape &sh = *cf->collisionShapes[q];
+            ty.push_back(sh.shape_type());
+            par.push_back(sh.center[0]); par.push_back(sh.center[1]); par.push_back(sh.center[2]); par.push_back(sh.shape_radius());
+        }
+        return check(admm_hip_set_collision_shapes(gpu, (int)ty.size(), ty.data(), par.data()));
+    }
 
     bool check(int rc) {
         if (rc == ADMM_OK) return true;

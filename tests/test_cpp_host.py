@@ -35,7 +35,7 @@ def have_gpu():
 
 
 def test_compiles_and_fails_loudly_without_gpu(pkg):
-    for name in ("singletet", "singlenode", "scene_bar"):
+    for name in ("singletet", "singlenode", "scene_bar", "scene_plinko"):
         exe = compile_cpp(name, pkg)
         assert os.path.exists(exe)
     if have_gpu():
@@ -105,3 +105,21 @@ def test_scene_through_class_api(pkg, tmp_path, typ):
         o.step(); elapsed += 0.04
         assert np.abs(X[fr] - o.x).max() < 2e-4, fr       # within the truncated-prox sensitivity
     assert np.abs(cp_final - np.array(list(o.force(h).pos))).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_plinko_scene_through_class_api(pkg, tmp_path):
+    g = golden("traj_collision.npz")
+    n = g["x"].shape[0]
+    inp = tmp_path / "in.bin"; outp = tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("3i", n, g["tets"].shape[0], g["types"].size))
+        f.write(g["x"].astype(np.float64).tobytes()); f.write(np.repeat(g["mass"], 3).tobytes()); f.write(g["tets"].astype(np.int32).tobytes())
+        f.write(g["types"].astype(np.int32).tobytes()); f.write(g["params"].astype(np.float64).tobytes())
+    frames = int(g["frames"][-1]) + 1
+    r = subprocess.run([compile_cpp("scene_plinko", pkg), str(inp), str(outp), str(frames), str(int(g["iters"]))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "weight 32" in r.stdout and "global_idx %d" % (9 * g["tets"].shape[0]) in r.stdout
+    X = np.fromfile(outp, dtype=np.float64).reshape(frames, 3 * n)
+    for fi, f in enumerate(g["frames"]):
+        assert np.abs(X[f] - g["x_frames"][fi]).max() < 1e-9      # the compiled reference's trajectory
