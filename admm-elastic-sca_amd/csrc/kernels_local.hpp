@@ -86,6 +86,33 @@ __device__ __forceinline__ void store_block_contiguous(double *lds, const double
 // Tets: KIND 0 = Neo-Hookean, 1 = StVK (HyperElasticTet, TetForce.cpp:320-364),
 //       2 = LinearTetStrain (:127-153), 3 = TetVolume (:173-210)
 // ---------------------------------------------------------------------------
+// the lane's inputs: B (stored corner order), Dx = D_i x, u
+__device__ __forceinline__ void tet_load(const BatchDev &b, const double *__restrict__ x, int e, int n, double (&B)[12], Mat3 &Dx, Mat3 &u) {
+    const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
+    const double *x0 = x + 3 * (size_t)id.x, *x1 = x + 3 * (size_t)id.y, *x2 = x + 3 * (size_t)id.z, *x3 = x + 3 * (size_t)id.w;
+    const double p0x = x0[0], p0y = x0[1], p0z = x0[2];
+    const double p1x = x1[0], p1y = x1[1], p1z = x1[2];
+    const double p2x = x2[0], p2y = x2[1], p2z = x2[2];
+    const double p3x = x3[0], p3y = x3[1], p3z = x3[2];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) B[i] = b.rest[(size_t)i * n + e];
+    // Dx(j, r) = sum_c B(c, r) * x_c[j], accumulated from 0 in stored corner order
+#define ADMM_DX(r, px0, px1, px2, px3) (((0.0 + B[0 + 4 * r] * px0) + B[1 + 4 * r] * px1) + B[2 + 4 * r] * px2) + B[3 + 4 * r] * px3
+    Dx.m00 = ADMM_DX(0, p0x, p1x, p2x, p3x); Dx.m10 = ADMM_DX(0, p0y, p1y, p2y, p3y); Dx.m20 = ADMM_DX(0, p0z, p1z, p2z, p3z);
+    Dx.m01 = ADMM_DX(1, p0x, p1x, p2x, p3x); Dx.m11 = ADMM_DX(1, p0y, p1y, p2y, p3y); Dx.m21 = ADMM_DX(1, p0z, p1z, p2z, p3z);
+    Dx.m02 = ADMM_DX(2, p0x, p1x, p2x, p3x); Dx.m12 = ADMM_DX(2, p0y, p1y, p2y, p3y); Dx.m22 = ADMM_DX(2, p0z, p1z, p2z, p3z);
+#undef ADMM_DX
+    if (b.dx_override) {
+        const double *o = b.dx_override;
+        Dx.m00 = o[(size_t)0 * n + e]; Dx.m10 = o[(size_t)1 * n + e]; Dx.m20 = o[(size_t)2 * n + e];
+        Dx.m01 = o[(size_t)3 * n + e]; Dx.m11 = o[(size_t)4 * n + e]; Dx.m21 = o[(size_t)5 * n + e];
+        Dx.m02 = o[(size_t)6 * n + e]; Dx.m12 = o[(size_t)7 * n + e]; Dx.m22 = o[(size_t)8 * n + e];
+    }
+    u.m00 = b.u[(size_t)0 * n + e]; u.m10 = b.u[(size_t)1 * n + e]; u.m20 = b.u[(size_t)2 * n + e];
+    u.m01 = b.u[(size_t)3 * n + e]; u.m11 = b.u[(size_t)4 * n + e]; u.m21 = b.u[(size_t)5 * n + e];
+    u.m02 = b.u[(size_t)6 * n + e]; u.m12 = b.u[(size_t)7 * n + e]; u.m22 = b.u[(size_t)8 * n + e];
+}
+
 template <int KIND, int M>
 #if ADMM_TET_WAVES > 0
 __global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
@@ -96,70 +123,42 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
     const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= n) return;
-    const bool live = true;
-    const int ec = e;
-    double f[12];
-    {
-        const int4 id = reinterpret_cast<const int4 *>(b.idx)[ec];
-        const double *x0 = x + 3 * (size_t)id.x, *x1 = x + 3 * (size_t)id.y, *x2 = x + 3 * (size_t)id.z, *x3 = x + 3 * (size_t)id.w;
-        const double p0x = x0[0], p0y = x0[1], p0z = x0[2];
-        const double p1x = x1[0], p1y = x1[1], p1z = x1[2];
-        const double p2x = x2[0], p2y = x2[1], p2z = x2[2];
-        const double p3x = x3[0], p3y = x3[1], p3z = x3[2];
-        double B[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) B[i] = b.rest[(size_t)i * n + ec];
-        // Dx(j, r) = sum_c B(c, r) * x_c[j], accumulated from 0 in stored corner order
-        Mat3 Dx;
-#define ADMM_DX(r, px0, px1, px2, px3) (((0.0 + B[0 + 4 * r] * px0) + B[1 + 4 * r] * px1) + B[2 + 4 * r] * px2) + B[3 + 4 * r] * px3
-        Dx.m00 = ADMM_DX(0, p0x, p1x, p2x, p3x); Dx.m10 = ADMM_DX(0, p0y, p1y, p2y, p3y); Dx.m20 = ADMM_DX(0, p0z, p1z, p2z, p3z);
-        Dx.m01 = ADMM_DX(1, p0x, p1x, p2x, p3x); Dx.m11 = ADMM_DX(1, p0y, p1y, p2y, p3y); Dx.m21 = ADMM_DX(1, p0z, p1z, p2z, p3z);
-        Dx.m02 = ADMM_DX(2, p0x, p1x, p2x, p3x); Dx.m12 = ADMM_DX(2, p0y, p1y, p2y, p3y); Dx.m22 = ADMM_DX(2, p0z, p1z, p2z, p3z);
-#undef ADMM_DX
-        if (b.dx_override) {
-            const double *o = b.dx_override;
-            Dx.m00 = o[(size_t)0 * n + ec]; Dx.m10 = o[(size_t)1 * n + ec]; Dx.m20 = o[(size_t)2 * n + ec];
-            Dx.m01 = o[(size_t)3 * n + ec]; Dx.m11 = o[(size_t)4 * n + ec]; Dx.m21 = o[(size_t)5 * n + ec];
-            Dx.m02 = o[(size_t)6 * n + ec]; Dx.m12 = o[(size_t)7 * n + ec]; Dx.m22 = o[(size_t)8 * n + ec];
-        }
-        Mat3 u;
-        u.m00 = b.u[(size_t)0 * n + ec]; u.m10 = b.u[(size_t)1 * n + ec]; u.m20 = b.u[(size_t)2 * n + ec];
-        u.m01 = b.u[(size_t)3 * n + ec]; u.m11 = b.u[(size_t)4 * n + ec]; u.m21 = b.u[(size_t)5 * n + ec];
-        u.m02 = b.u[(size_t)6 * n + ec]; u.m12 = b.u[(size_t)7 * n + ec]; u.m22 = b.u[(size_t)8 * n + ec];
-        const Mat3 F = mat_add(Dx, u);
-        Mat3 z;
-        if (KIND <= 1) {
-            const double mu = b.par[(size_t)0 * n + ec], lambda = b.par[(size_t)1 * n + ec];
-            const int maxIter = (int)b.par[(size_t)2 * n + ec];
-            double sa = b.state[(size_t)0 * n + ec], sb = b.state[(size_t)1 * n + ec], sc = b.state[(size_t)2 * n + ec], hs = b.state[(size_t)3 * n + ec];
-            int it = 0;
-            z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it);
-            if (live) {
-                b.state[(size_t)0 * n + e] = sa; b.state[(size_t)1 * n + e] = sb; b.state[(size_t)2 * n + e] = sc; b.state[(size_t)3 * n + e] = hs;
-                b.n_iters[e] = it;
-            }
-        } else {
-            const double lmin = (KIND == 3) ? b.par[(size_t)1 * n + ec] : 0.0, lmax = (KIND == 3) ? b.par[(size_t)2 * n + ec] : 0.0;
-            const Mat3 p = project_tet_p<KIND == 3>(F, lmin, lmax);
-            const double k = b.kblend[ec], w2 = b.w2[ec];
-            const double den = w2 + k;
-            z.m00 = (k * p.m00 + w2 * F.m00) / den; z.m10 = (k * p.m10 + w2 * F.m10) / den; z.m20 = (k * p.m20 + w2 * F.m20) / den;
-            z.m01 = (k * p.m01 + w2 * F.m01) / den; z.m11 = (k * p.m11 + w2 * F.m11) / den; z.m21 = (k * p.m21 + w2 * F.m21) / den;
-            z.m02 = (k * p.m02 + w2 * F.m02) / den; z.m12 = (k * p.m12 + w2 * F.m12) / den; z.m22 = (k * p.m22 + w2 * F.m22) / den;
-        }
-        // u += Dx - z ; q = z - u
-        Mat3 q;
-#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (live) { b.u[(size_t)row * n + e] = un; b.z[(size_t)row * n + e] = z.mm; } }
-        ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
+    double B[12];
+    Mat3 Dx, u, F, z;
+    tet_load(b, x, e, n, B, Dx, u);
+    F = mat_add(Dx, u);
+    if (KIND <= 1) {
+        const double mu = b.par[(size_t)0 * n + e], lambda = b.par[(size_t)1 * n + e];
+        const int maxIter = (int)b.par[(size_t)2 * n + e];
+        double sa = b.state[(size_t)0 * n + e], sb = b.state[(size_t)1 * n + e], sc = b.state[(size_t)2 * n + e], hs = b.state[(size_t)3 * n + e];
+        int it = 0;
+        z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it);
+        b.state[(size_t)0 * n + e] = sa; b.state[(size_t)1 * n + e] = sb; b.state[(size_t)2 * n + e] = sc; b.state[(size_t)3 * n + e] = hs;
+        b.n_iters[e] = it;
+    } else {
+        const double lmin = (KIND == 3) ? b.par[(size_t)1 * n + e] : 0.0, lmax = (KIND == 3) ? b.par[(size_t)2 * n + e] : 0.0;
+        const Mat3 p = project_tet_p<KIND == 3>(F, lmin, lmax);
+        const double k = b.kblend[e], w2 = b.w2[e];
+        const double den = w2 + k;
+        z.m00 = (k * p.m00 + w2 * F.m00) / den; z.m10 = (k * p.m10 + w2 * F.m10) / den; z.m20 = (k * p.m20 + w2 * F.m20) / den;
+        z.m01 = (k * p.m01 + w2 * F.m01) / den; z.m11 = (k * p.m11 + w2 * F.m11) / den; z.m21 = (k * p.m21 + w2 * F.m21) / den;
+        z.m02 = (k * p.m02 + w2 * F.m02) / den; z.m12 = (k * p.m12 + w2 * F.m12) / den; z.m22 = (k * p.m22 + w2 * F.m22) / den;
+    }
+    // (Measured and dropped: re-deriving B, Dx, u from memory here instead of keeping them live
+    // across the projection saves ~20 VGPRs but not enough for a third wave per SIMD: -2 %.)
+    // u += Dx - z ; q = z - u
+    Mat3 q;
+#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; b.u[(size_t)row * n + e] = un; b.z[(size_t)row * n + e] = z.mm; }
+    ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
 #undef ADMM_UZ
-        const double s = b.w2h2[ec];
-        // f_c[j] = s * sum_r B(c, r) q(j, r)
+    const double s = b.w2h2[e];
+    // f_c[j] = s * sum_r B(c, r) q(j, r)
+    double f[12];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f[3 * c + 0] = s * ((B[c] * q.m00 + B[c + 4] * q.m01) + B[c + 8] * q.m02);
-            f[3 * c + 1] = s * ((B[c] * q.m10 + B[c + 4] * q.m11) + B[c + 8] * q.m12);
-            f[3 * c + 2] = s * ((B[c] * q.m20 + B[c + 4] * q.m21) + B[c + 8] * q.m22);
-        }
+    for (int c = 0; c < 4; ++c) {
+        f[3 * c + 0] = s * ((B[c] * q.m00 + B[c + 4] * q.m01) + B[c + 8] * q.m02);
+        f[3 * c + 1] = s * ((B[c] * q.m10 + B[c + 4] * q.m11) + B[c + 8] * q.m12);
+        f[3 * c + 2] = s * ((B[c] * q.m20 + B[c + 4] * q.m21) + B[c + 8] * q.m22);
     }
     const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
     double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
