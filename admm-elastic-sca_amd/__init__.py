@@ -345,3 +345,33 @@ def make_bar_system(nx, ny, nz, kind=KIND["TET_NH"], mu=1e5, lam=1e5, max_iter=5
         s.set_shard(rank, world)
     s.n_tets = tets.shape[0]
     return s
+
+
+def make_mixed_system(nx, ny, nz, cloth_w, cloth_l, device_id=0, dt=0.04, rank=0, world=1, stream=None):
+    """BASELINE.md section 4 config 5 ("mixed scene"): a bar whose lower half (in z) is Neo-Hookean and
+    upper half StVK (tets first), then a sym-plane cloth with LimitedTriangleStrain (k=100,
+    limits .95/1.05) + BendForce (k=20) hanging from two corner anchors, bar face anchored, gravity.
+    Returns (system, description dict with the arrays the oracle needs)."""
+    x, tets = meshgen.bar(nx, ny, nz)
+    m = meshgen.lumped_tet_mass(x, tets, 1000.0)
+    half = tets.shape[0] // 2
+    xc, tris = meshgen.sym_plane(cloth_w, cloth_l, size=1.0)
+    xc = xc + np.array([3.0, 1.0, 0.0])
+    hinges = meshgen.bend_hinges(tris)
+    off = x.shape[0]
+    X = np.concatenate([x, xc])
+    M = np.concatenate([m, np.full(xc.shape[0], 0.5 / xc.shape[0])])
+    s = System(device_id=device_id, stream=stream)
+    s.set_timestep(dt)
+    s.add_nodes(X.ravel(), np.repeat(M, 3))
+    desc = dict(X=X, M=M, forces=[
+        ("TET_NH", tets[:half], [1e5, 1e5, 5]), ("TET_STVK", tets[half:], [1e5, 1e5, 5]),
+        ("TRI_STRAIN", tris + off, [100.0, 0.95, 1.05, 1.0]), ("BEND", hinges + off, [20.0]),
+        ("ANCHOR", np.concatenate([meshgen.bar_anchor_nodes(nx, ny), np.array([off, off + cloth_w], dtype=np.int32)]), [-1.0, 1.0])])
+    for name, idx, par in desc["forces"]:
+        s.add_forces(KIND[name], idx, par)
+    s.add_gravity((0.0, -9.8, 0.0))
+    if world > 1:
+        s.set_shard(rank, world)
+    s.n_elements = tets.shape[0] + tris.shape[0]
+    return s, desc

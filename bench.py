@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--dims", type=int, nargs=3, default=[32, 32, 163], help="bar cubes nx ny nz (default: the 1M-tet bar)")
+    p.add_argument("--config", choices=["bar", "mixed"], default="bar", help="bar = configs[3] (headline); mixed = configs[4]: 500k NH+StVK tets + 100k cloth tris")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-dims", type=int, nargs=3, default=[16, 16, 65], help="bounded CPU-baseline sample (cubes)")
     return p.parse_args()
@@ -100,7 +101,14 @@ def main():
     nx, ny, nz = a.dims
     stream = torch.cuda.current_stream()
     t0 = time.time()
-    s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=rank, world=world, stream=stream.cuda_stream)
+    if a.config == "mixed":      # BASELINE.json configs[4]: 26x26x123 cubes = 498,888 tets (half NH, half StVK) + 158x158 sym-plane cloth
+        if a.dims == [32, 32, 163]:
+            nx, ny, nz = 26, 26, 123
+        s, _desc = pkg.make_mixed_system(nx, ny, nz, 158, 158, device_id=local_rank, rank=rank, world=world, stream=stream.cuda_stream)
+        s.n_tets = s.n_elements
+        a.no_cpu_baseline = True
+    else:
+        s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=rank, world=world, stream=stream.cuda_stream)
     if world > 1:
         n3 = None
         holder = {}
@@ -184,8 +192,10 @@ def main():
         "value": value, "unit": "ADMM iters/s x elements", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "NH bar %dx%dx%d cubes (Kuhn split) = %d tets, %d nodes, mu=lambda=1e5, max_iterations 5, rho 1000, h 0.05, "
-                               "z=0 face anchored, g=-9.8, dt 0.04, %d ADMM iters/frame" % (nx, ny, nz, n_tets, info["n_nodes"], ADMM_ITERS),
+        "config": {"workload": ("NH bar %dx%dx%d cubes (Kuhn split) = %d tets, %d nodes, mu=lambda=1e5, max_iterations 5, rho 1000, h 0.05, "
+                                "z=0 face anchored, g=-9.8, dt 0.04, %d ADMM iters/frame" % (nx, ny, nz, n_tets, info["n_nodes"], ADMM_ITERS)) if a.config == "bar" else
+                               ("mixed scene: bar %dx%dx%d (half NH, half StVK tets) + 158x158 sym-plane cloth (triangle strain + bend) + anchors = %d "
+                                "tets+tris, %d nodes, %d ADMM iters/frame" % (nx, ny, nz, n_tets, info["n_nodes"], ADMM_ITERS)),
                    "admm_iters_per_step": ADMM_ITERS, "parallelism": "elements sharded x%d, RHS all-reduce, replicated solve" % world,
                    "nnz_L": info["nnz_L"], "supernodes": info["n_supernodes"], "levels": info["n_levels"],
                    "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"], "host_threads": info["host_threads"]},

@@ -458,3 +458,24 @@ def test_explicit_forces(pkg):
     s.set_gravity(w, [0.0, 0.0, 0.0])            # direction is host-mutable (windyflag.cpp:141-152)
     s.step(5)
     assert np.isfinite(s.m_x).all()
+
+
+def test_mixed_scene(pkg):
+    """config 5 in miniature: NH + StVK tets, cloth (triangle strain + bend) and anchors in one step;
+    two disconnected bodies in one factorization."""
+    s, d = pkg.make_mixed_system(4, 3, 9, 8, 6)
+    s.initialize()
+    o = Oracle(); o.settings(0.04, 1)
+    o.add_nodes(d["X"].ravel(), np.repeat(d["M"], 3))
+    for name, idx, par in d["forces"]:
+        o.add_forces(KIND[name], idx, par)
+    o.add_gravity([0, -9.8, 0])
+    assert o.initialize()
+    assert s.info()["rows_compact"] == o.rows
+    b = np.random.default_rng(0).normal(size=3 * s.n_nodes)
+    assert np.abs(s.apply_A(s.solve_only(b)) - b).max() < 1e-10 * np.abs(b).max()
+    s.step(1); o.step()
+    assert np.abs(s.m_x - o.x).max() < 1e-10
+    for _ in range(3):
+        s.step(20)
+    assert np.isfinite(s.m_x).all()
