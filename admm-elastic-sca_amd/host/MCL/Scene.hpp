@@ -1,0 +1,630 @@
+// Scene.hpp -- headless restatement of the parts of mclscene / trimesh2 that the
+// reference's scene ingest (src/SimContext.cpp, src/ForceBuilder.{hpp,cpp}) goes
+// through, so the shipped XML scenes can be loaded on a box with no GL stack:
+//
+//   XML text -> Component / Param lists          (deps/mclscene/include/MCL/Param.hpp:122-201,
+//                                                 deps/mclscene/src/SceneManager.cpp:37-147)
+//   scale / translate / rotate -> xform          (Param.hpp:132-160: the matrix is written to TEXT with
+//                                                 the stream's default 6 significant digits and parsed
+//                                                 back, so a 20 degree rotation carries 6-digit cosines;
+//                                                 trimesh2 include/XForm.h:122-143,311-330,474-484,487-523)
+//   tetmesh: <File>.node/.ele -> float vertices  (deps/mclscene/src/TetMesh.cpp:133-228; surface 231-271)
+//   plane: make_sym_plane                        (trimesh2 include/TriMeshBuilder.h:24-59,116-171)
+//   across-edge face adjacency (bend hinges)     (trimesh2 libsrc/TriMesh_connectivity.cc:58-134)
+//
+// Everything the solver reads is reproduced bit for bit: vertices are `float`, the
+// transform is applied in double and rounded back to float per coordinate, and the
+// same libstdc++ stream conversions parse and print the numbers.  What is NOT here:
+// rendering data (normals, tstrips, textures, materials, lights, cameras, BVH) and
+// mclscene's tessellators for sphere/box/beam/cylinder/torus and its ply/obj readers.
+// Such objects are accepted as static scenery (their parameters are kept, which is
+// all the samples read from them); giving one a <Force> is an error.
+//
+// Bit parity with the reference needs the arithmetic below compiled without FMA
+// contraction (-ffp-contract=off, the default x86-64 baseline has no FMA anyway).
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace trimesh {
+
+template <int D, class T> struct Vec {
+    T v[D];
+    Vec() { for (int i = 0; i < D; ++i) v[i] = T(0); }
+    Vec(T a, T b) { v[0] = a; v[1] = b; }
+    Vec(T a, T b, T c) { v[0] = a; v[1] = b; v[2] = c; }
+    T &operator[](int i) { return v[i]; }
+    const T &operator[](int i) const { return v[i]; }
+    typedef T value_type;
+};
+typedef Vec<3, float> vec;
+typedef Vec<3, float> point;
+typedef Vec<3, float> vec3;
+typedef Vec<2, float> vec2;
+typedef Vec<4, float> vec4;
+
+// 4x4, column-major, double (trimesh2's `xform`)
+struct xform {
+    double m[16];
+    xform() { for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+    double &operator[](int i) { return m[i]; }
+    const double &operator[](int i) const { return m[i]; }
+    static xform identity() { return xform(); }
+    static xform trans(double tx, double ty, double tz) { xform r; r[12] = tx; r[13] = ty; r[14] = tz; return r; }
+    static xform scale(double sx, double sy, double sz) { xform r; r[0] = sx; r[5] = sy; r[10] = sz; return r; }
+    // angle in radians about (rx, ry, rz); XForm.h:126-143
+    static xform rot(double angle, double rx, double ry, double rz) {
+        const double l = std::sqrt(rx * rx + ry * ry + rz * rz);
+        if (l == 0.0) return xform();
+        const double l1 = 1.0 / l, x = rx * l1, y = ry * l1, z = rz * l1;
+        const double s = std::sin(angle), c = std::cos(angle);
+        const double xs = x * s, ys = y * s, zs = z * s, c1 = 1.0 - c;
+        const double xx = c1 * x * x, yy = c1 * y * y, zz = c1 * z * z;
+        const double xy = c1 * x * y, xz = c1 * x * z, yz = c1 * y * z;
+        xform r;
+        r[0] = xx + c;  r[1] = xy + zs; r[2] = xz - ys;  r[3] = 0;
+        r[4] = xy - zs; r[5] = yy + c;  r[6] = yz + xs;  r[7] = 0;
+        r[8] = xz + ys; r[9] = yz - xs; r[10] = zz + c;  r[11] = 0;
+        r[12] = 0; r[13] = 0; r[14] = 0; r[15] = 1;
+        return r;
+    }
+    template <class S> static xform rot(double angle, const S &axis) { return rot(angle, axis[0], axis[1], axis[2]); }
+};
+
+// XForm.h:311-330: each entry is a left-to-right sum of four products
+static inline xform operator*(const xform &a, const xform &b) {
+    xform r;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            r[i + 4 * j] = a[i] * b[4 * j] + a[i + 4] * b[4 * j + 1] + a[i + 8] * b[4 * j + 2] + a[i + 12] * b[4 * j + 3];
+    return r;
+}
+
+// XForm.h:474-484: homogeneous transform of a float point, evaluated in double, rounded per coordinate
+static inline point operator*(const xform &xf, const point &p) {
+    const double v0 = (double)p[0], v1 = (double)p[1], v2 = (double)p[2];
+    const double h = 1.0 / (xf[3] * v0 + xf[7] * v1 + xf[11] * v2 + xf[15]);
+    return point((float)(h * (xf[0] * v0 + xf[4] * v1 + xf[8] * v2 + xf[12])),
+                 (float)(h * (xf[1] * v0 + xf[5] * v1 + xf[9] * v2 + xf[13])),
+                 (float)(h * (xf[2] * v0 + xf[6] * v1 + xf[10] * v2 + xf[14])));
+}
+
+// XForm.h:487-500: row by row, stream default formatting
+static inline std::ostream &operator<<(std::ostream &os, const xform &m) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            os << m[i + 4 * j];
+            if (j == 3) os << std::endl; else os << " ";
+        }
+    return os;
+}
+// XForm.h:501-523: three rows are mandatory, the fourth may be absent
+static inline std::istream &operator>>(std::istream &is, xform &m) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) is >> m[i + 4 * j];
+    if (!is.good()) { m = xform::identity(); return is; }
+    for (int j = 0; j < 4; ++j) is >> m[3 + 4 * j];
+    if (!is.good()) { m[3] = m[7] = m[11] = 0.0; m[15] = 1.0; is.clear(); return is; }
+    return is;
+}
+
+// The subset of trimesh2's TriMesh the solver side touches.
+struct TriMesh {
+    struct Face {
+        int v[3];
+        Face() { v[0] = v[1] = v[2] = 0; }
+        Face(int a, int b, int c) { v[0] = a; v[1] = b; v[2] = c; }
+        int &operator[](int i) { return v[i]; }
+        const int &operator[](int i) const { return v[i]; }
+        int indexof(int x) const { return v[0] == x ? 0 : v[1] == x ? 1 : v[2] == x ? 2 : -1; }
+    };
+    std::vector<point> vertices;
+    std::vector<Face> faces;
+    std::vector<std::vector<int> > adjacentfaces; // faces around each vertex, ascending face id
+    std::vector<Face> across_edge;                // face opposite corner j of face f, -1 on the boundary
+    void need_faces() {}
+    void need_normals() {} // rendering only
+    void need_tstrips() { need_across_edge(); }
+    void need_adjacentfaces() {
+        if (!adjacentfaces.empty() || faces.empty()) return;
+        adjacentfaces.resize(vertices.size());
+        for (size_t f = 0; f < faces.size(); ++f) for (int j = 0; j < 3; ++j) adjacentfaces[faces[f][j]].push_back((int)f);
+    }
+    // TriMesh_connectivity.cc:92-134: the neighbour across edge (v1,v2) is the first face around v1
+    // that also touches v2 and runs the edge the other way
+    void need_across_edge() {
+        if (!across_edge.empty()) return;
+        need_adjacentfaces();
+        if (adjacentfaces.empty()) return;
+        const int nf = (int)faces.size();
+        across_edge.assign(nf, Face(-1, -1, -1));
+        for (int i = 0; i < nf; ++i)
+            for (int j = 0; j < 3; ++j) {
+                if (across_edge[i][j] != -1) continue;
+                const int v1 = faces[i][(j + 1) % 3], v2 = faces[i][(j + 2) % 3];
+                const std::vector<int> &a1 = adjacentfaces[v1], &a2 = adjacentfaces[v2];
+                for (size_t k = 0; k < a1.size(); ++k) {
+                    const int other = a1[k];
+                    if (other == i) continue;
+                    if (std::find(a2.begin(), a2.end(), other) == a2.end()) continue;
+                    const int ind = (faces[other].indexof(v1) + 1) % 3;
+                    if (faces[other][(ind + 1) % 3] != v2) continue;
+                    across_edge[i][j] = other;
+                    across_edge[other][ind] = i;
+                    break;
+                }
+            }
+    }
+};
+
+static inline void apply_xform(TriMesh *mesh, const xform &xf) {
+    for (size_t i = 0; i < mesh->vertices.size(); ++i) mesh->vertices[i] = xf * mesh->vertices[i];
+}
+
+// TriMeshBuilder.h:116-171: (tess_x+1)(tess_y+1) grid nodes, x outer / y inner, in [-1,1]^2 at z=0,
+// then one centre node per cell; four faces per cell (ll,lr,c) (lr,ur,c) (c,ur,ul) (ll,c,ul).
+// Coordinates are float expressions.
+static inline void make_sym_plane(TriMesh *mesh, int tess_x, int tess_y) {
+    if (tess_x < 1) tess_x = 1;
+    if (tess_y < 1) tess_y = 1;
+    mesh->vertices.reserve((tess_x + 1) * (tess_y + 1) + tess_x * tess_y);
+    for (int x = 0; x < tess_x + 1; ++x)
+        for (int y = 0; y < tess_y + 1; ++y) {
+            const float xp = -1.0f + 2.0f * x / tess_x, yp = -1.0f + 2.0f * y / tess_y;
+            mesh->vertices.push_back(point(xp, yp, 0));
+        }
+    for (int x = 0; x < tess_x; ++x)
+        for (int y = 0; y < tess_y; ++y) {
+            float xp = -1.0f + 2.0f * x / tess_x, yp = -1.0f + 2.0f * y / tess_y;
+            xp += 1.f / tess_x;
+            yp += 1.f / tess_y;
+            mesh->vertices.push_back(point(xp, yp, 0));
+        }
+    mesh->faces.reserve(tess_x * tess_y * 4);
+    for (int x = 0; x < tess_x; ++x)
+        for (int y = 0; y < tess_y; ++y) {
+            const int ll = y + x * (tess_y + 1), lr = y + (x + 1) * (tess_y + 1), ul = ll + 1, ur = lr + 1;
+            const int cent = (tess_x + 1) * (tess_y + 1) + x * tess_y + y;
+            mesh->faces.push_back(TriMesh::Face(ll, lr, cent));
+            mesh->faces.push_back(TriMesh::Face(lr, ur, cent));
+            mesh->faces.push_back(TriMesh::Face(cent, ur, ul));
+            mesh->faces.push_back(TriMesh::Face(ll, cent, ul));
+        }
+}
+
+} // namespace trimesh
+
+namespace mcl {
+
+namespace parse {
+static inline std::string to_lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
+static inline std::string fileDir(std::string fname) {
+    const size_t pos = fname.find_last_of('/');
+    return (std::string::npos == pos) ? "" : fname.substr(0, pos) + '/';
+}
+} // namespace parse
+
+// ---- the XML subset the scene files use: nested elements with attributes, comments, a declaration.
+// ---- Like the reference's pugixml use, several top-level elements are allowed and text is ignored.
+namespace xml {
+struct Node {
+    std::string name;
+    std::vector<std::pair<std::string, std::string> > attrs;
+    std::vector<Node> children;
+    // value of attribute `key`, "" if absent (pugi::xml_attribute::as_string/value of a null attribute)
+    std::string attribute(const std::string &key) const {
+        for (size_t i = 0; i < attrs.size(); ++i) if (attrs[i].first == key) return attrs[i].second;
+        return "";
+    }
+};
+
+class Reader {
+public:
+    explicit Reader(const std::string &text) : s(text), p(0) {}
+    // children of a synthetic document node
+    bool parse(Node &doc) {
+        while (true) {
+            skip_misc();
+            if (p >= s.size()) return true;
+            if (s[p] != '<') { ++p; continue; }
+            Node n;
+            if (!element(n)) return false;
+            doc.children.push_back(n);
+        }
+    }
+private:
+    const std::string &s;
+    size_t p;
+    bool starts(const char *t) const { return s.compare(p, std::char_traits<char>::length(t), t) == 0; }
+    void skip_ws() { while (p < s.size() && std::isspace((unsigned char)s[p])) ++p; }
+    // whitespace, text, comments, <? ?> and <! > outside tags
+    void skip_misc() {
+        while (p < s.size()) {
+            if (starts("<!--")) { const size_t e = s.find("-->", p + 4); p = (e == std::string::npos) ? s.size() : e + 3; }
+            else if (starts("<?")) { const size_t e = s.find("?>", p + 2); p = (e == std::string::npos) ? s.size() : e + 2; }
+            else if (starts("<!")) { const size_t e = s.find('>', p + 2); p = (e == std::string::npos) ? s.size() : e + 1; }
+            else if (s[p] == '<') return;
+            else ++p;
+        }
+    }
+    static bool name_char(char c) { return std::isalnum((unsigned char)c) || c == '_' || c == '-' || c == ':' || c == '.'; }
+    std::string name() { const size_t b = p; while (p < s.size() && name_char(s[p])) ++p; return s.substr(b, p - b); }
+    static std::string unescape(const std::string &v) {
+        if (v.find('&') == std::string::npos) return v;
+        static const char *ent[5] = {"&amp;", "&lt;", "&gt;", "&quot;", "&apos;"};
+        static const char rep[5] = {'&', '<', '>', '"', '\''};
+        std::string o;
+        for (size_t i = 0; i < v.size();) {
+            bool hit = false;
+            if (v[i] == '&')
+                for (int e = 0; e < 5 && !hit; ++e) {
+                    const size_t n = std::char_traits<char>::length(ent[e]);
+                    if (v.compare(i, n, ent[e]) == 0) { o += rep[e]; i += n; hit = true; }
+                }
+            if (!hit) o += v[i++];
+        }
+        return o;
+    }
+    bool element(Node &n) {
+        ++p; // '<'
+        n.name = name();
+        if (n.name.empty()) return false;
+        while (true) {
+            skip_ws();
+            if (p >= s.size()) return false;
+            if (starts("/>")) { p += 2; return true; }
+            if (s[p] == '>') { ++p; break; }
+            const std::string key = name();
+            if (key.empty()) return false;
+            skip_ws();
+            if (p >= s.size() || s[p] != '=') return false;
+            ++p; skip_ws();
+            if (p >= s.size() || (s[p] != '"' && s[p] != '\'')) return false;
+            const char q = s[p++];
+            const size_t e = s.find(q, p);
+            if (e == std::string::npos) return false;
+            n.attrs.push_back(std::make_pair(key, unescape(s.substr(p, e - p))));
+            p = e + 1;
+        }
+        while (true) { // content
+            skip_misc();
+            if (p >= s.size()) return false;
+            if (starts("</")) { const size_t e = s.find('>', p); if (e == std::string::npos) return false; p = e + 1; return true; }
+            Node c;
+            if (!element(c)) return false;
+            n.children.push_back(c);
+        }
+    }
+};
+
+static inline bool load_file(const std::string &filename, Node &doc) {
+    std::ifstream f(filename.c_str(), std::ios::in | std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string text = ss.str();
+    Reader r(text);
+    return r.parse(doc);
+}
+// first top-level element whose lower-cased name is `lname`, or an empty node
+static inline const Node *find_head(const Node &doc, const std::string &lname) {
+    for (size_t i = 0; i < doc.children.size(); ++i) if (parse::to_lower(doc.children[i].name) == lname) return &doc.children[i];
+    return 0;
+}
+} // namespace xml
+
+// A parameter is (lower-case tag, value text); conversions go through a stringstream (Param.hpp:74-99,209-236)
+class Param {
+public:
+    Param(std::string tag_, std::string value_) : tag(tag_), value(value_) {}
+    double as_double() const { std::stringstream ss(value); double v; ss >> v; return v; }
+    char as_char() const { std::stringstream ss(value); char v; ss >> v; return v; }
+    std::string as_string() const { return value; }
+    int as_int() const { std::stringstream ss(value); int v; ss >> v; return v; }
+    long as_long() const { std::stringstream ss(value); long v; ss >> v; return v; }
+    bool as_bool() const { std::stringstream ss(value); bool v; ss >> v; return v; }
+    float as_float() const { std::stringstream ss(value); float v; ss >> v; return v; }
+    trimesh::vec4 as_vec4() const { std::stringstream ss(value); trimesh::vec4 v; for (int i = 0; i < 4; ++i) ss >> v[i]; return v; }
+    trimesh::vec as_vec3() const { std::stringstream ss(value); trimesh::vec v; for (int i = 0; i < 3; ++i) ss >> v[i]; return v; }
+    trimesh::vec2 as_vec2() const { std::stringstream ss(value); trimesh::vec2 v; for (int i = 0; i < 2; ++i) ss >> v[i]; return v; }
+    trimesh::xform as_xform() const { trimesh::xform x; std::stringstream ss(value); ss >> x; return x; }
+    std::string tag;
+    std::string value;
+};
+
+class Component {
+public:
+    Component(std::string tag_, std::string name_, std::string type_) : tag(tag_), name(name_), type(type_) {}
+    std::string tag, name, type;
+    // a missing parameter is appended with an empty value (Param.hpp:268-275)
+    Param &get(std::string t) {
+        for (size_t i = 0; i < params.size(); ++i) if (params[i].tag == t) return params[i];
+        params.push_back(Param(t, ""));
+        return params.back();
+    }
+    Param &operator[](std::string t) { return get(t); }
+    bool exists(std::string t) const {
+        for (size_t i = 0; i < params.size(); ++i) if (params[i].tag == t) return true;
+        return false;
+    }
+    std::vector<Param> params;
+};
+
+// Param.hpp:122-166.  scale / translate / rotate values are replaced by the TEXT of the 4x4 matrix.
+static inline void load_params(std::vector<Param> &params, const xml::Node &node) {
+    for (size_t c = 0; c < node.children.size(); ++c) {
+        const std::string tag = parse::to_lower(node.children[c].name);
+        const std::string value = node.children[c].attribute("value");
+        Param p(tag, value);
+        if (tag == "scale" || tag == "translate" || tag == "rotate") {
+            std::stringstream ss(value);
+            trimesh::vec v; ss >> v[0] >> v[1] >> v[2];
+            trimesh::xform xf;
+            if (tag == "scale") xf = trimesh::xform::scale(v[0], v[1], v[2]);
+            else if (tag == "translate") xf = trimesh::xform::trans(v[0], v[1], v[2]);
+            else {
+                const float to_rad = (float)(M_PI / 180.f); // degrees -> radians on float components
+                for (int i = 0; i < 3; ++i) v[i] *= to_rad;
+                trimesh::xform rot;
+                rot = rot * trimesh::xform::rot(v[0], trimesh::vec(1.f, 0.f, 0.f));
+                rot = rot * trimesh::xform::rot(v[1], trimesh::vec(0.f, 1.f, 0.f));
+                rot = rot * trimesh::xform::rot(v[2], trimesh::vec(0.f, 0.f, 1.f));
+                xf = rot;
+            }
+            std::stringstream out; out << xf;
+            p.value = out.str();
+        }
+        params.push_back(p);
+    }
+}
+
+class BaseObject {
+public:
+    virtual ~BaseObject() {}
+    virtual std::string get_type() const = 0;
+    virtual void update() {}
+    virtual const std::shared_ptr<trimesh::TriMesh> get_TriMesh() { return std::shared_ptr<trimesh::TriMesh>(); }
+    virtual void apply_xform(const trimesh::xform &) {}
+    virtual std::string get_material() const { return ""; }
+    virtual void set_material(std::string) {}
+};
+
+class TriangleMesh : public BaseObject {
+public:
+    TriangleMesh(std::shared_ptr<trimesh::TriMesh> tm, std::string mat = "") : tris(tm), vertices(tm->vertices), faces(tm->faces), material(mat) {}
+    std::string get_type() const { return "trimesh"; }
+    const std::shared_ptr<trimesh::TriMesh> get_TriMesh() { return tris; }
+    void apply_xform(const trimesh::xform &xf) { trimesh::apply_xform(tris.get(), xf); }
+    std::string get_material() const { return material; }
+    void set_material(std::string mat) { material = mat; }
+    std::shared_ptr<trimesh::TriMesh> tris;
+    std::vector<trimesh::point> &vertices;
+    std::vector<trimesh::TriMesh::Face> &faces;
+private:
+    std::string material;
+};
+
+// Scenery whose geometry only mclscene's tessellators can make (sphere, box, cylinder, ...): parameters only.
+class StaticShape : public BaseObject {
+public:
+    StaticShape(std::string type_, std::string mat = "") : type(type_), material(mat) {}
+    std::string get_type() const { return type; }
+    std::string get_material() const { return material; }
+    void set_material(std::string mat) { material = mat; }
+private:
+    std::string type, material;
+};
+
+// sorted vertex triple + the byte hash mclscene keys its face-count table with
+// (include/MCL/VertexSort.hpp:55-75,103-112); the table's iteration order is the order of a tet mesh's surface faces
+struct int3 {
+    int3() {}
+    int3(int a, int b, int c) {
+        sorted_v[0] = a; sorted_v[1] = b; sorted_v[2] = c;
+        if (sorted_v[0] > sorted_v[1]) std::swap(sorted_v[0], sorted_v[1]);
+        if (sorted_v[0] > sorted_v[2]) std::swap(sorted_v[0], sorted_v[2]);
+        if (sorted_v[1] > sorted_v[2]) std::swap(sorted_v[1], sorted_v[2]);
+        orig_v[0] = a; orig_v[1] = b; orig_v[2] = c;
+    }
+    bool operator==(const int3 &o) const { return sorted_v[0] == o.sorted_v[0] && sorted_v[1] == o.sorted_v[1] && sorted_v[2] == o.sorted_v[2]; }
+    int sorted_v[3], orig_v[3];
+};
+struct int3_hash {
+    size_t operator()(const int3 &k) const {
+        const unsigned char *in = reinterpret_cast<const unsigned char *>(k.sorted_v);
+        unsigned int ret = 2654435761u;
+        for (size_t i = 0; i < 3 * sizeof(int); ++i) ret = (ret * 2654435761u) ^ *in++;
+        return ret;
+    }
+};
+
+class TetMesh : public BaseObject {
+    std::shared_ptr<trimesh::TriMesh> tris; // vertex / surface container
+public:
+    struct tet {
+        tet() {}
+        tet(int a, int b, int c, int d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
+        int v[4];
+    };
+    std::vector<tet> tets;
+    std::vector<trimesh::point> &vertices;        // ALL nodes, as float
+    std::vector<trimesh::TriMesh::Face> &faces;   // boundary triangles
+    TetMesh(std::string mat = "") : tris(new trimesh::TriMesh), vertices(tris->vertices), faces(tris->faces), material(mat) {}
+    std::string get_type() const { return "tetmesh"; }
+    const std::shared_ptr<trimesh::TriMesh> get_TriMesh() { return tris; }
+    void apply_xform(const trimesh::xform &xf) { trimesh::apply_xform(tris.get(), xf); }
+    std::string get_material() const { return material; }
+    void set_material(std::string mat) { material = mat; }
+    void need_normals(bool = true) {}
+
+    // `filename` without extension; TetGen .node/.ele (0- or 1-based ids). ply input needs tetgen: not here.
+    bool load(std::string filename) {
+        vertices.clear(); tets.clear(); faces.clear();
+        const size_t dot = filename.find_last_of('.');
+        if (dot != std::string::npos && parse::to_lower(filename.substr(dot + 1)) == "ply") {
+            std::cerr << "\n**TetMesh Error: tetrahedralising " << filename << " needs tetgen, which this headless loader does not carry" << std::endl;
+            return false;
+        }
+        return load_node(filename) && load_ele(filename) && need_surface();
+    }
+
+private:
+    std::string material;
+
+    // TetMesh.cpp:133-178: "<count> ..." header line, then "<id> <x> <y> <z>" per line
+    bool load_node(const std::string &filename) {
+        const std::string path = filename + ".node";
+        std::ifstream in(path.c_str());
+        if (!in) { std::cerr << "\n**TetMesh Error: Could not load " << path << std::endl; return false; }
+        std::string line;
+        std::getline(in, line);
+        int n_nodes = 0; { std::stringstream hs(line); hs >> n_nodes; }
+        vertices.resize(n_nodes);
+        std::vector<int> seen(n_nodes, 0);
+        bool one_based = false;
+        for (int i = 0; i < n_nodes; ++i) {
+            std::getline(in, line);
+            std::stringstream ls(line);
+            double x, y, z; int id;
+            ls >> id >> x >> y >> z;
+            if (i == 0 && id == 1) one_based = true;
+            if (one_based) id -= 1;
+            if (id < 0 || id >= n_nodes) { std::cerr << "\n**TetMesh Error: Your indices are bad for file " << path << std::endl; return false; }
+            vertices[id] = trimesh::point((float)x, (float)y, (float)z);
+            seen[id] = 1;
+        }
+        for (int i = 0; i < n_nodes; ++i) if (!seen[i]) { std::cerr << "\n**TetMesh Error: Your indices are bad for file " << path << std::endl; return false; }
+        return true;
+    }
+    // TetMesh.cpp:180-228
+    bool load_ele(const std::string &filename) {
+        const std::string path = filename + ".ele";
+        std::ifstream in(path.c_str());
+        if (!in) { std::cerr << "\n**TetMesh Error: Could not load " << path << std::endl; return false; }
+        std::string line;
+        std::getline(in, line);
+        int n_tets = 0; { std::stringstream hs(line); hs >> n_tets; }
+        tets.resize(n_tets);
+        std::vector<int> seen(n_tets, 0);
+        bool one_based = false;
+        for (int i = 0; i < n_tets; ++i) {
+            std::getline(in, line);
+            std::stringstream ls(line);
+            int id, n[4];
+            ls >> id >> n[0] >> n[1] >> n[2] >> n[3];
+            if (i == 0 && id == 1) one_based = true;
+            if (one_based) { id -= 1; for (int j = 0; j < 4; ++j) n[j] -= 1; }
+            if (id < 0 || id >= n_tets) { std::cerr << "\n**TetMesh Error: Your indices are bad for file " << path << std::endl; return false; }
+            for (int j = 0; j < 4; ++j) if (n[j] < 0 || n[j] >= (int)vertices.size()) { std::cerr << "\n**TetMesh Error: element " << id << " of " << path << " names a node that does not exist" << std::endl; return false; }
+            tets[id] = tet(n[0], n[1], n[2], n[3]);
+            seen[id] = 1;
+        }
+        for (int i = 0; i < n_tets; ++i) if (!seen[i]) { std::cerr << "\n**TetMesh Error: Your indices are bad for file " << path << std::endl; return false; }
+        return true;
+    }
+    // TetMesh.cpp:231-271: faces used by exactly one tet, in the count table's iteration order
+    bool need_surface() {
+        std::unordered_map<int3, int, int3_hash> count;
+        for (size_t t = 0; t < tets.size(); ++t) {
+            const int p0 = tets[t].v[0], p1 = tets[t].v[1], p2 = tets[t].v[2], p3 = tets[t].v[3];
+            const int3 f[4] = {int3(p0, p1, p3), int3(p0, p2, p1), int3(p0, p3, p2), int3(p1, p2, p3)};
+            for (int k = 0; k < 4; ++k) {
+                if (count.count(f[k]) == 0) count[f[k]] = 1;
+                else count[f[k]] += 1;
+            }
+        }
+        for (std::unordered_map<int3, int, int3_hash>::iterator it = count.begin(); it != count.end(); ++it)
+            if (it->second == 1) faces.push_back(trimesh::TriMesh::Face(it->first.orig_v[0], it->first.orig_v[1], it->first.orig_v[2]));
+        return true;
+    }
+};
+
+// DefaultBuilders.hpp:50-304 for the two object types a force can be attached to; everything else -> StaticShape
+static inline std::shared_ptr<BaseObject> default_build_object(Component &obj) {
+    const std::string type = parse::to_lower(obj.type);
+    trimesh::xform x_form;
+    std::string material = "";
+    for (size_t i = 0; i < obj.params.size(); ++i) {
+        const std::string tag = parse::to_lower(obj.params[i].tag);
+        if (tag == "translate" || tag == "scale" || tag == "rotate") x_form = x_form * obj.params[i].as_xform();
+        else if (tag == "material") material = obj.params[i].as_string();
+    }
+    if (type == "plane") {
+        std::shared_ptr<trimesh::TriMesh> tris(new trimesh::TriMesh());
+        int width = 10, length = 10;
+        double noise = 0.0;
+        for (size_t i = 0; i < obj.params.size(); ++i) {
+            const std::string tag = parse::to_lower(obj.params[i].tag);
+            if (tag == "width") width = obj.params[i].as_int();
+            else if (tag == "length") length = obj.params[i].as_int();
+            else if (tag == "noise") noise = obj.params[i].as_double();
+        }
+        if (noise > 0.0) throw std::runtime_error("\n**Scene Error: object \"" + obj.name + "\": <noise> uses trimesh2's random noisify, which this loader does not carry");
+        trimesh::make_sym_plane(tris.get(), width, length);
+        tris->need_tstrips();
+        std::shared_ptr<BaseObject> o(new TriangleMesh(tris, material));
+        o->apply_xform(x_form);
+        return o;
+    }
+    if (type == "tetmesh") {
+        std::shared_ptr<TetMesh> mesh(new TetMesh(material));
+        std::string filename = "";
+        for (size_t i = 0; i < obj.params.size(); ++i) if (parse::to_lower(obj.params[i].tag) == "file") filename = obj.params[i].as_string();
+        if (!filename.size()) throw std::runtime_error("\n**TetMesh Error for obj " + obj.name + ": No file specified");
+        if (!mesh->load(filename)) throw std::runtime_error("\n**TetMesh Error for obj " + obj.name + ": failed to load file " + filename);
+        std::shared_ptr<BaseObject> o(mesh);
+        o->apply_xform(x_form);
+        return o;
+    }
+    return std::shared_ptr<BaseObject>(new StaticShape(type, material));
+}
+
+typedef std::function<std::shared_ptr<BaseObject>(Component &)> BuildObjCallback;
+
+// SceneManager.cpp:37-147 without cameras, lights, materials and the BVH
+class SceneManager {
+public:
+    SceneManager() { createObject = default_build_object; }
+    bool load(std::string filename) {
+        xml::Node doc;
+        if (!xml::load_file(filename, doc)) { std::cerr << "\n**SceneManager::load_xml Error: Unable to load " << filename << std::endl; return false; }
+        const std::string xmldir = parse::fileDir(filename);
+        const xml::Node *head = xml::find_head(doc, "mclscene");
+        std::vector<Component> components;
+        for (size_t c = 0; head && c < head->children.size(); ++c) {
+            const xml::Node &n = head->children[c];
+            const std::string name = n.attribute("name"), type = n.attribute("type");
+            if (name.size() == 0 || type.size() == 0) { std::cerr << "\n**SceneManager::load_xml Error: Component \"" << n.name << "\" need a name and type." << std::endl; return false; }
+            std::vector<Param> params;
+            load_params(params, n);
+            for (size_t i = 0; i < params.size(); ++i) {
+                const std::string t = parse::to_lower(params[i].tag);
+                if (t == "file" || t == "texture") params[i].value = xmldir + params[i].as_string();
+            }
+            components.push_back(Component(n.name, name, type));
+            components.back().params = params;
+        }
+        for (size_t j = 0; j < components.size(); ++j) {
+            if (parse::to_lower(components[j].tag) != "object") continue; // cameras, lights, materials: rendering only
+            const std::string name = parse::to_lower(components[j].name);
+            std::shared_ptr<BaseObject> obj = createObject(components[j]);
+            if (obj) { objects.push_back(obj); objects_map[name] = obj; object_params[name] = components[j].params; }
+        }
+        return true;
+    }
+    std::vector<std::shared_ptr<BaseObject> > objects;
+    std::unordered_map<std::string, std::shared_ptr<BaseObject> > objects_map;   // lower-case name -> object
+    std::unordered_map<std::string, std::vector<Param> > object_params;          // parameters in file order
+    BuildObjCallback createObject;
+};
+
+} // namespace mcl

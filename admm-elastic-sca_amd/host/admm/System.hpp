@@ -24,7 +24,7 @@ namespace admm {
 
 class System {
 public:
-    System() : elapsed_s(0.0), initialized(false), gpu(nullptr), device_id(0) {}
+    System() : elapsed_s(0.0), device_id(0), initialized(false), gpu(nullptr) {}
     ~System() { if (gpu) admm_hip_destroy(gpu); }
     System(const System &) = delete;
     System &operator=(const System &) = delete;

@@ -13,6 +13,10 @@
 #include "TetForce.hpp"
 #include "TriangleForce.hpp"
 #include <cstring>
+#include "CollisionCylinder.hpp"
+#include "CollisionFloor.hpp"
+#include "CollisionSphere.hpp"
+#include "CollisionForce.hpp"
 
 #include "../include/admm_kinds.h"
 
@@ -50,7 +54,79 @@ int refscene_get_force(void *h, int i, int *idx, double *p) {
     if (BendForce *t = dynamic_cast<BendForce *>(f)) { for (int j = 0; j < 4; ++j) idx[j] = t->idx[j]; p[0] = t->stiffness; return ADMM_KIND_BEND; }
     if (Spring *t = dynamic_cast<Spring *>(f)) { idx[0] = t->idx0; idx[1] = t->idx1; p[0] = t->stiffness; return ADMM_KIND_SPRING; }
     if (StaticAnchor *t = dynamic_cast<StaticAnchor *>(f)) { idx[0] = t->idx; p[0] = t->weight; p[1] = 1.0; return ADMM_KIND_ANCHOR; }
+    if (CollisionForce *t = dynamic_cast<CollisionForce *>(f)) { idx[0] = (int)t->collisionShapes.size(); p[0] = t->weight; return ADMM_KIND_COLLISION; }
     return -1;
+}
+
+// names of scene->object_params in the reference's own (unordered_map) iteration order, '\n'-joined;
+// the sample programs and SimContext::initialize walk the objects in this order
+int refscene_object_order(void *h, char *buf, int cap) {
+    SimContext *c = (SimContext *)h; std::string s;
+    for (auto it = c->scene->object_params.begin(); it != c->scene->object_params.end(); ++it) { s += it->first; s += "\n"; }
+    if ((int)s.size() + 1 > cap) return -1;
+    std::memcpy(buf, s.c_str(), s.size() + 1); return (int)c->scene->object_params.size();
+}
+// surface/triangle faces of a named object as the loader left them (-1: no such object / no mesh)
+int refscene_n_faces(void *h, const char *name) {
+    SimContext *c = (SimContext *)h; if (!c->scene->objects_map.count(name)) return -1;
+    std::shared_ptr<trimesh::TriMesh> m = c->scene->objects_map[name]->get_TriMesh(); return m ? (int)m->faces.size() : -1;
+}
+int refscene_n_vertices(void *h, const char *name) {
+    SimContext *c = (SimContext *)h; if (!c->scene->objects_map.count(name)) return -1;
+    std::shared_ptr<trimesh::TriMesh> m = c->scene->objects_map[name]->get_TriMesh(); return m ? (int)m->vertices.size() : -1;
+}
+void refscene_get_faces(void *h, const char *name, int *out) {
+    SimContext *c = (SimContext *)h; std::shared_ptr<trimesh::TriMesh> m = c->scene->objects_map[name]->get_TriMesh();
+    for (size_t f = 0; f < m->faces.size(); ++f) for (int j = 0; j < 3; ++j) out[3 * f + j] = m->faces[f][j];
+}
+// WindForce face list (node triples) of explicit force i, 0 if it is not a wind force
+int refscene_wind_size(void *h, int i) { WindForce *w = dynamic_cast<WindForce *>(((SimContext *)h)->system->explicit_forces[i].get()); return w ? (int)w->tris.size() : 0; }
+void refscene_get_wind(void *h, int i, int *out) { WindForce *w = dynamic_cast<WindForce *>(((SimContext *)h)->system->explicit_forces[i].get()); std::memcpy(out, w->tris.data(), sizeof(int) * w->tris.size()); }
+
+// cylinders of CollisionForce i: (cx, cy, cz, radius) per shape, in list order
+void refscene_get_cylinders(void *h, int i, double *out) {
+    CollisionForce *t = dynamic_cast<CollisionForce *>(((SimContext *)h)->system->forces[i].get());
+    for (size_t s = 0; s < t->collisionShapes.size(); ++s) {
+        CollisionCylinder *c = dynamic_cast<CollisionCylinder *>(t->collisionShapes[s].get());
+        for (int j = 0; j < 3; ++j) out[4 * s + j] = c->center[j];
+        out[4 * s + 3] = c->radius;
+    }
+}
+
+// ---- what the sample mains do between load() and initialize() (samples/*/*.cpp), so whole-scene
+// ---- trajectories can be generated without the GL application
+void refscene_set_x(void *h, const double *x) { SimContext *c = (SimContext *)h; std::memcpy(c->system->m_x.data(), x, sizeof(double) * c->system->m_x.size()); }
+void refscene_add_static_anchor(void *h, int idx) { ((SimContext *)h)->system->forces.push_back(std::shared_ptr<Force>(new StaticAnchor(idx))); }
+// samples/windyflag/windyflag.cpp:98-128: wind over the faces of every object that has a force
+void refscene_add_wind(void *h, const double *dir) {
+    SimContext *c = (SimContext *)h; std::vector<int> faces; int total = 0;
+    for (auto it = c->scene->object_params.begin(); it != c->scene->object_params.end(); ++it) {
+        bool has_force = false;
+        for (size_t p = 0; p < it->second.size(); ++p) if (it->second[p].tag == "force") has_force = true;
+        if (!has_force) continue;
+        std::shared_ptr<trimesh::TriMesh> m = c->scene->objects_map[it->first]->get_TriMesh();
+        for (size_t f = 0; f < m->faces.size(); ++f) for (int j = 0; j < 3; ++j) faces.push_back(m->faces[f][j] + total);
+        total += (int)m->vertices.size();
+    }
+    std::shared_ptr<ExplicitForce> w(new WindForce(faces));
+    w->direction = Eigen::Vector3d(dir[0], dir[1], dir[2]);
+    c->system->explicit_forces.push_back(w);
+}
+// samples/plinkopony/plinkopony.cpp:53-96: one CollisionCylinder per object named c*, then one CollisionForce
+int refscene_add_cylinder_collision(void *h) {
+    SimContext *c = (SimContext *)h; std::vector<std::shared_ptr<CollisionShape> > shapes;
+    for (auto it = c->scene->object_params.begin(); it != c->scene->object_params.end(); ++it) {
+        if (it->first[0] != 'c') continue;
+        double rad = 1.f; Eigen::Vector3d center(0, 0, 0), scale(1, 1, 1);
+        for (size_t i = 0; i < it->second.size(); ++i) {
+            if (it->second[i].tag == "scale_copy") { trimesh::vec v = it->second[i].as_vec3(); scale = Eigen::Vector3d(v[0], v[1], v[2]); }
+            else if (it->second[i].tag == "translate_copy") { trimesh::vec v = it->second[i].as_vec3(); center = Eigen::Vector3d(v[0], v[1], v[2]); }
+            else if (it->second[i].tag == "radius") rad = it->second[i].as_double();
+        }
+        shapes.push_back(std::shared_ptr<CollisionShape>(new CollisionCylinder(center, scale, rad)));
+    }
+    ((SimContext *)h)->system->forces.push_back(std::shared_ptr<Force>(new CollisionForce(shapes)));
+    return (int)shapes.size();
 }
 
 } // extern "C"
