@@ -19,11 +19,11 @@ from . import meshgen  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libadmm_hip.so")
 
-KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8)
-KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1]
-KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3]
-KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1]
-KIND_STATE = [0, 0, 0, 0, 4, 4, 0, 0, 0]
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8, TRI_AREA=9, TRI_FUNG=10)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1, 3, 3]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3, 6, 6]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1, 4, 3]
+KIND_STATE = [0, 0, 0, 0, 4, 4, 0, 0, 0, 0, 4]
 SHAPE = dict(FLOOR=0, SPHERE=1, CYLINDER=2)
 EXPLICIT = dict(CONST=0, WIND=1)
 

@@ -52,9 +52,13 @@ struct Explicit {
     int type = 0; double dir[3] = {0, 0, 0};
     std::vector<int32_t> idx;            // CONST: node ids (empty = all); WIND: [n][3] triangle node ids
     int n = 0;                            // nodes / triangles
-    int *d_idx = nullptr; double *d_force = nullptr; int64_t *d_ptr = nullptr; int *d_tri_of = nullptr;
+    int *d_idx = nullptr;                 // WIND: triangles sorted by dependency level (see wind_serial_kernel)
+    int *d_level_ptr = nullptr; int n_levels = 0;
 };
 
+#ifndef ADMM_BWD_BIG_CW
+#define ADMM_BWD_BIG_CW 1            // backward kernel: columns per wave on levels with supernodes wider than 64
+#endif
 struct LevelDev {
     int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
     int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
@@ -140,7 +144,7 @@ void element_G(int kind, const double *rest, double G[4][3], int &cols) {
     case ADMM_KIND_SPRING: cols = 1; G[0][0] = 1.0; G[1][0] = -1.0; break;
     case ADMM_KIND_TET_LINEAR: case ADMM_KIND_TET_VOLUME: case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK:
         cols = 3; for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) G[c][r] = rest[c + 4 * r]; break;
-    case ADMM_KIND_TRI_STRAIN: cols = 2; for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) G[c][r] = rest[c + 3 * r]; break;
+    case ADMM_KIND_TRI_STRAIN: case ADMM_KIND_TRI_AREA: case ADMM_KIND_TRI_FUNG: cols = 2; for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) G[c][r] = rest[c + 3 * r]; break;
     case ADMM_KIND_BEND: cols = 3; G[0][0] = 1.0; G[2][0] = -1.0; G[3][1] = 1.0; G[2][1] = -1.0; G[1][2] = 1.0; G[2][2] = -1.0; break;
     default: cols = 0;
     }
@@ -256,7 +260,7 @@ int upload_factor(admm_hip_ctx *ctx) {
         std::vector<int> ssn, stile, bsn, btile, wsn, wchunk;
         int maxk = 0;
         for (int s : F.levels[l]) maxk = std::max(maxk, F.sn[s].ncols);
-        L.bwd_cw = (maxk <= 64) ? 4 : 1;          // columns per wave in the backward kernel
+        L.bwd_cw = (maxk <= 64) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
         for (int s : F.levels[l]) {
             const Supernode &S = F.sn[s];
             const int f = S.ncols + S.nrows;
@@ -296,7 +300,8 @@ int upload_all(admm_hip_ctx *ctx) {
         const int end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
         b.n_local = end - b.first;
         b.slot_base = slot;
-        const bool sort_corners = (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TRI_STRAIN);
+        const bool is_tri = b.kind == ADMM_KIND_TRI_STRAIN || b.kind == ADMM_KIND_TRI_AREA || b.kind == ADMM_KIND_TRI_FUNG;
+        const bool sort_corners = (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) || is_tri;
         b.max_iter = 0;
         if (b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK)
             for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
@@ -330,7 +335,7 @@ int upload_all(admm_hip_ctx *ctx) {
             const double *R = &b.rest[(size_t)e * 12];
             if (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) {
                 for (int c = 0; c < 4; ++c) for (int r = 0; r < 3; ++r) rest[(size_t)(c + 4 * r) * nl + el] = R[ord[c] + 4 * r];
-            } else if (b.kind == ADMM_KIND_TRI_STRAIN) {
+            } else if (b.kind == ADMM_KIND_TRI_STRAIN || b.kind == ADMM_KIND_TRI_AREA || b.kind == ADMM_KIND_TRI_FUNG) {
                 for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) rest[(size_t)(c + 3 * r) * nl + el] = R[ord[c] + 3 * r];
             } else {
                 for (int i = 0; i < 12; ++i) rest[(size_t)i * nl + el] = R[i];
@@ -367,16 +372,23 @@ int upload_all(admm_hip_ctx *ctx) {
         std::vector<int> pidx(E.idx.size());
         for (size_t i = 0; i < E.idx.size(); ++i) pidx[i] = F.iperm[E.idx[i]];
         E.d_idx = nullptr;
-        if (!pidx.empty()) TRY(upload(ctx, &E.d_idx, pidx));
-        if (E.type == ADMM_EXPLICIT_WIND) {
-            TRY(dalloc(ctx, &E.d_force, 3 * (size_t)std::max(E.n, 1)));
-            std::vector<int64_t> ptr(n + 1, 0);
-            for (int t = 0; t < E.n; ++t) for (int c = 0; c < 3; ++c) ptr[pidx[3 * (size_t)t + c] + 1]++;
-            for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-            std::vector<int> tri_of(ptr[n]); std::vector<int64_t> pos(ptr.begin(), ptr.end() - 1);
-            for (int t = 0; t < E.n; ++t) for (int c = 0; c < 3; ++c) tri_of[pos[pidx[3 * (size_t)t + c]]++] = t;   // ascending triangle order per node
-            TRY(upload(ctx, &E.d_ptr, ptr)); TRY(upload(ctx, &E.d_tri_of, tri_of));
-        }
+        if (E.type == ADMM_EXPLICIT_WIND && E.n) {
+            // dependency levels of the serial loop: level(t) = 1 + max level of earlier triangles sharing a node
+            std::vector<int> last(n, 0), lev(E.n);
+            int nlev = 0;
+            for (int t = 0; t < E.n; ++t) {
+                const int *q = &pidx[3 * (size_t)t];
+                const int l = 1 + std::max(last[q[0]], std::max(last[q[1]], last[q[2]]));
+                lev[t] = l; last[q[0]] = last[q[1]] = last[q[2]] = l; nlev = std::max(nlev, l);
+            }
+            std::vector<int> lptr(nlev + 1, 0);
+            for (int t = 0; t < E.n; ++t) lptr[lev[t]]++;            // level l (1-based) counted into lptr[l]
+            for (int l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];   // lptr[l] = end of level l = start of level l+1
+            std::vector<int> pos(lptr.begin(), lptr.end() - 1), sorted(pidx.size());
+            for (int t = 0; t < E.n; ++t) { const int d = pos[lev[t] - 1]++; for (int c = 0; c < 3; ++c) sorted[3 * (size_t)d + c] = pidx[3 * (size_t)t + c]; }
+            E.n_levels = nlev;
+            TRY(upload(ctx, &E.d_idx, sorted)); TRY(upload(ctx, &E.d_level_ptr, lptr));
+        } else if (!pidx.empty()) TRY(upload(ctx, &E.d_idx, pidx));
     }
     HIPCHK(hipDeviceSynchronize());
     ctx->info.t_upload_s = now_s() - t0;
@@ -426,7 +438,9 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
         case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel<0>, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TRI_AREA: hipLaunchKernelGGL(project_tri_kernel<1>, grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TRI_FUNG: hipLaunchKernelGGL(project_tri_kernel<2>, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_COLLISION: hipLaunchKernelGGL(project_collision_kernel, grid, block, 0, ctx->stream, d, x, (const ShapeTable *)ctx->d_shapes); break;
         default: return fail(ctx, ADMM_ERR_UNSUPPORTED, "no kernel for kind %d", b.kind);
         }
@@ -464,6 +478,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_bwd) {
             if (L.bwd_cw == 4) hipLaunchKernelGGL(solve_bwd_kernel<4>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 2) hipLaunchKernelGGL(solve_bwd_kernel<2>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
             else hipLaunchKernelGGL(solve_bwd_kernel<1>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
         }
     }
@@ -714,8 +729,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
                 const int cnt = E.idx.empty() ? ctx->n_nodes : E.n;
                 if (cnt) hipLaunchKernelGGL(explicit_const_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, cnt, (const int *)E.d_idx, ctx->dt, E.dir[0], E.dir[1], E.dir[2], ctx->d_v);
             } else if (E.n) {
-                hipLaunchKernelGGL(wind_force_kernel, dim3((E.n + 255) / 256), dim3(256), 0, ctx->stream, E.n, (const int *)E.d_idx, ctx->dt, E.dir[0], E.dir[1], E.dir[2], ctx->d_x, ctx->d_v, E.d_force);
-                hipLaunchKernelGGL(wind_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, E.d_ptr, E.d_tri_of, E.d_force, ctx->d_v);
+                hipLaunchKernelGGL(wind_serial_kernel, dim3(1), dim3(1024), 0, ctx->stream, E.n_levels, (const int *)E.d_level_ptr, (const int *)E.d_idx, ctx->dt, E.dir[0], E.dir[1], E.dir[2], ctx->d_x, ctx->d_v);
             }
         }
         hipLaunchKernelGGL(xbar_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);

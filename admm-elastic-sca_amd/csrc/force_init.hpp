@@ -6,7 +6,7 @@
 // Reference (deps/admm-elastic-sca/src/system/):
 //   helper::init_tet_force            TetForce.cpp:28-57
 //   LinearTetStrain/TetVolume/HyperElasticTet::initialize  TetForce.cpp:112-117,160-163,303-310
-//   LimitedTriangleStrain::initialize TriangleForce.cpp:29-63
+//   LimitedTriangleStrain::initialize TriangleForce.cpp:29-63 (TriArea inherits it); FungTriangle::initialize :171-210
 //   BendForce::initialize             BendForce.cpp:26-56
 //   Spring::initialize                Force.cpp:29-38
 //   StaticAnchor ctor / initialize    AnchorForce.hpp:57-60, AnchorForce.cpp:31-35
@@ -113,10 +113,16 @@ inline bool force_initialize(int kind, const int *idx, const double *params, con
         *weight = sqrtf((float)stiff) * sqrtf((float)vol);
         return true;
     }
-    case ADMM_KIND_TRI_STRAIN: {
+    case ADMM_KIND_TRI_STRAIN: case ADMM_KIND_TRI_AREA: {   // TriArea inherits LimitedTriangleStrain::initialize
         double B[6]; const double area = tri_rest(idx, x, B);
         for (int i = 0; i < 6; ++i) rest[i] = B[i];
         *weight = sqrtf((float)params[0]) * sqrtf((float)area);
+        return true;
+    }
+    case ADMM_KIND_TRI_FUNG: {    // FungTriangle::initialize, TriangleForce.cpp:171-210: double sqrt
+        double B[6]; const double area = tri_rest(idx, x, B);
+        for (int i = 0; i < 6; ++i) rest[i] = B[i];
+        *weight = std::sqrt(params[0]) * std::sqrt(area);
         return true;
     }
     case ADMM_KIND_BEND:
@@ -131,7 +137,7 @@ inline bool force_initialize(int kind, const int *idx, const double *params, con
 inline double force_measure(int kind, const int *idx, const double *x) {
     double tmp[12];
     if (kind == ADMM_KIND_TET_LINEAR || kind == ADMM_KIND_TET_VOLUME || kind == ADMM_KIND_TET_NH || kind == ADMM_KIND_TET_STVK) return tet_rest(idx, x, tmp);
-    if (kind == ADMM_KIND_TRI_STRAIN) return tri_rest(idx, x, tmp);
+    if (kind == ADMM_KIND_TRI_STRAIN || kind == ADMM_KIND_TRI_AREA || kind == ADMM_KIND_TRI_FUNG) return tri_rest(idx, x, tmp);
     return 0.0;
 }
 

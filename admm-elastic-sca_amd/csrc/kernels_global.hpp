@@ -52,37 +52,48 @@ __global__ void explicit_const_kernel(int n, const int *__restrict__ idx, double
     v[3 * (size_t)node] += (dt * gx); v[3 * (size_t)node + 1] += (dt * gy); v[3 * (size_t)node + 2] += (dt * gz);
 }
 
-// WindForce::project, ExplicitForce.cpp:42-98, in two deterministic passes: (1) the force of
-// every triangle from the velocity field as it stands, (2) per node, the sum over its
-// incident wind triangles in triangle order.
-__global__ void wind_force_kernel(int n_tris, const int *__restrict__ tris, double dt, double wx, double wy, double wz,
-                                  const double *__restrict__ x, const double *__restrict__ v, double *__restrict__ force) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    const size_t i0 = 3 * (size_t)tris[3 * t], i1 = 3 * (size_t)tris[3 * t + 1], i2 = 3 * (size_t)tris[3 * t + 2];
+// WindForce::project, ExplicitForce.cpp:42-98, with the result of the reference's loop run
+// serially (OMP_NUM_THREADS=1): triangle i sees the velocities already incremented by the
+// triangles before it, and every node receives its increments in triangle order.  The host
+// sorts the triangles into dependency levels (a triangle's level is one more than the highest
+// level among earlier triangles sharing a node with it), so the triangles of one level touch
+// disjoint nodes and can run side by side; one workgroup walks the levels with a barrier in
+// between.  Once per frame, O(#levels) barriers (a few hundred for a cloth sheet).
+__global__ __launch_bounds__(1024) void wind_serial_kernel(int n_levels, const int *__restrict__ level_ptr, const int *__restrict__ tris,
+                                                           double dt, double wx, double wy, double wz, const double *__restrict__ x, double *v) {
     const double dir[3] = {wx, wy, wz};
-    double vr[3], a[3], b[3];
+    for (int l = 0; l < n_levels; ++l) {
+        for (int t = level_ptr[l] + (int)threadIdx.x; t < level_ptr[l + 1]; t += (int)blockDim.x) {
+            const size_t i[3] = {3 * (size_t)tris[3 * t], 3 * (size_t)tris[3 * t + 1], 3 * (size_t)tris[3 * t + 2]};
+            double vr[3], a[3], b[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        vr[j] = (v[i0 + j] + v[i1 + j] + v[i2 + j]) / 3.0 - dir[j];
-        a[j] = x[i1 + j] - x[i0 + j]; b[j] = x[i2 + j] - x[i0 + j];
+            for (int j = 0; j < 3; ++j) {
+                const double v0 = __hip_atomic_load(&v[i[0] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double v1 = __hip_atomic_load(&v[i[1] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double v2 = __hip_atomic_load(&v[i[2] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vr[j] = (v0 + v1 + v2) / 3.0 - dir[j];
+                a[j] = x[i[1] + j] - x[i[0] + j]; b[j] = x[i[2] + j] - x[i[0] + j];
+            }
+            const double n0 = a[1] * b[2] - a[2] * b[1], n1 = a[2] * b[0] - a[0] * b[2], n2 = a[0] * b[1] - a[1] * b[0];
+            const double nn = sqrt(n0 * n0 + (n1 * n1 + n2 * n2));
+            const double nm[3] = {n0 / nn, n1 / nn, n2 / nn};
+            const double area = 0.5 * nn;
+            const double v_n = nm[0] * vr[0] + (nm[1] * vr[1] + nm[2] * vr[2]);
+            const double c = -1000.0 * area * v_n * fabs(v_n);
+            double f[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { f[j] = c * nm[j]; f[j] *= 0.33; f[j] *= dt; }
+            // corner by corner, re-reading: a triangle naming one node twice increments it twice
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double cur = __hip_atomic_load(&v[i[q] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&v[i[q] + j], cur + f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        __threadfence();
+        __syncthreads();
     }
-    const double n0 = a[1] * b[2] - a[2] * b[1], n1 = a[2] * b[0] - a[0] * b[2], n2 = a[0] * b[1] - a[1] * b[0];
-    const double nn = sqrt(n0 * n0 + (n1 * n1 + n2 * n2));
-    const double nm[3] = {n0 / nn, n1 / nn, n2 / nn};
-    const double area = 0.5 * nn;
-    const double v_n = nm[0] * vr[0] + (nm[1] * vr[1] + nm[2] * vr[2]);
-    const double c = -1000.0 * area * v_n * fabs(v_n);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { double f = c * nm[j]; f *= 0.33; f *= dt; force[3 * (size_t)t + j] = f; }
-}
-__global__ void wind_gather_kernel(int n_nodes, const int64_t *__restrict__ ptr, const int *__restrict__ tri_of, const double *__restrict__ force, double *__restrict__ v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n_nodes) return;
-    const int node = i / 3, c = i - 3 * node;
-    double vi = v[i];
-    for (int64_t p = ptr[node]; p < ptr[node + 1]; ++p) vi += force[3 * (size_t)tri_of[p] + c];
-    v[i] = vi;
 }
 
 // m_v = (curr_x - m_x) * (1/dt) ; m_x = curr_x             (System.cpp:70-71)
@@ -205,6 +216,12 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
 // (supernode, 64-row tile); the 16 waves split the columns, partial sums are
 // combined through LDS in wave order.
 constexpr int FWD_BIG_KCHUNK = 2048;
+#ifndef ADMM_FWD_DEPTH
+#define ADMM_FWD_DEPTH 8          // panel columns per load group in the big forward kernel
+#endif
+#ifndef ADMM_BWD_UNROLL
+#define ADMM_BWD_UNROLL 4         // 64-row groups per load batch in the CW = 1 backward kernel
+#endif
 template <bool CG2>
 __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_tile,
                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
@@ -243,10 +260,12 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
         const int jb = c0 + wave * per;
         int je = min(jb + per, c0 + kc);
         je = row_ok ? min(je, jend) : jb;
-        // first group of this wave's panel columns in flight before the staging barrier
-        double pre[8];
+        // first group of this wave's panel columns in flight before the staging barrier; after it the
+        // next group is always requested before the current one is consumed (two groups in flight)
+        constexpr int D = ADMM_FWD_DEPTH;
+        double cur[D], nxt[D];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pre[q] = (jb + q < je) ? P[(size_t)f * (jb + q)] : 0.0;
+        for (int q = 0; q < D; ++q) cur[q] = (jb + q < je) ? P[(size_t)f * (jb + q)] : 0.0;
         __syncthreads();
         for (int q = threadIdx.x; q < kc; q += 1024) {
             const double *src = y + 3 * (size_t)(first + c0 + q);
@@ -255,24 +274,14 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
             ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
         }
         __syncthreads();
-        {
-            const double *t = &ts[3 * (jb - c0)];
+        for (int j = jb; j < je; j += D) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (jb + q < je) { a0 += pre[q] * t[3 * q]; a1 += pre[q] * t[3 * q + 1]; a2 += pre[q] * t[3 * q + 2]; }
-        }
-        int j = jb + 8;
-        for (; j + 8 <= je; j += 8) {
-            double p[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) p[q] = P[(size_t)f * (j + q)];
+            for (int q = 0; q < D; ++q) nxt[q] = (j + D + q < je) ? P[(size_t)f * (j + D + q)] : 0.0;
             const double *t = &ts[3 * (j - c0)];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { a0 += p[q] * t[3 * q]; a1 += p[q] * t[3 * q + 1]; a2 += p[q] * t[3 * q + 2]; }
-        }
-        for (; j < je; ++j) {
-            const double p0 = P[(size_t)f * j];
-            const double *t = &ts[3 * (j - c0)];
-            a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+            for (int q = 0; q < D; ++q) if (j + q < je) { a0 += cur[q] * t[3 * q]; a1 += cur[q] * t[3 * q + 1]; a2 += cur[q] * t[3 * q + 2]; }
+#pragma unroll
+            for (int q = 0; q < D; ++q) cur[q] = nxt[q];
         }
     }
     red[wave][3 * lane] = a0; red[wave][3 * lane + 1] = a1; red[wave][3 * lane + 2] = a2;
@@ -330,12 +339,13 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
         if (j0 < k) {
             if (CW == 1) {
                 int q = lane;
-                for (; q + 192 < rc; q += 256) {
-                    double p[4];
+                constexpr int U = ADMM_BWD_UNROLL;
+                for (; q + 64 * (U - 1) < rc; q += 64 * U) {
+                    double p[U];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = r0 + q + 64 * u; p[u] = (i >= j0) ? Pj[i] : 0.0; }
+                    for (int u = 0; u < U; ++u) { const int i = r0 + q + 64 * u; p[u] = (i >= j0) ? Pj[i] : 0.0; }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const double *v = &vs[3 * (q + 64 * u)]; acc[0][0] += p[u] * v[0]; acc[0][1] += p[u] * v[1]; acc[0][2] += p[u] * v[2]; }
+                    for (int u = 0; u < U; ++u) { const double *v = &vs[3 * (q + 64 * u)]; acc[0][0] += p[u] * v[0]; acc[0][1] += p[u] * v[1]; acc[0][2] += p[u] * v[2]; }
                 }
                 for (; q < rc; q += 64) {
                     const int i = r0 + q;

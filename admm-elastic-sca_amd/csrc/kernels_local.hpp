@@ -321,6 +321,10 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, c
 // agrees with the reference's QR-preconditioned Jacobi SVD to rounding
 // (tests state the tolerance; this kernel is not bit-exact by construction).
 // ---------------------------------------------------------------------------
+// MODE 0: LimitedTriangleStrain (above).  MODE 1: TriArea (TriangleForce.cpp:251-295) and MODE 2:
+// FungTriangle (:227-249) need the singular values and vectors themselves: they run the bit-exact
+// restatement of Eigen's 3x2 JacobiSVD (local_math.hpp svd32).
+template <int MODE>
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) {
     const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
@@ -341,36 +345,51 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
             d[3 * r + j] = dx[3 * r + j] + u[3 * r + j];
         }
     }
-    // C = F^T F (2x2), polar factor T = F C^{-1/2}
-    const double c00 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    const double c01 = d[0] * d[3] + d[1] * d[4] + d[2] * d[5];
-    const double c11 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
-    const double detC = c00 * c11 - c01 * c01;
-    double T[6];
-    {
-        // sqrt of SPD 2x2: S = (C + sqrt(det) I) / sqrt(tr + 2 sqrt(det)); T = F S^-1
-        const double sd = sqrt(detC > 0.0 ? detC : 0.0);
-        const double tr = c00 + c11;
-        const double den = sqrt(tr + 2.0 * sd);
-        const double s00 = (c00 + sd) / den, s01 = c01 / den, s11 = (c11 + sd) / den;
-        const double ds = s00 * s11 - s01 * s01;
-        const double i00 = s11 / ds, i01 = -s01 / ds, i11 = s00 / ds;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { T[j] = d[j] * i00 + d[3 + j] * i01; T[3 + j] = d[j] * i01 + d[3 + j] * i11; }
-    }
-    const double k = b.kblend[e], w2 = b.w2[e], s = b.w2h2[e];
     double zi[6];
+    const double s = b.w2h2[e];
+    if (MODE == 0) {
+        // C = F^T F (2x2), polar factor T = F C^{-1/2}
+        const double c00 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const double c01 = d[0] * d[3] + d[1] * d[4] + d[2] * d[5];
+        const double c11 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+        const double detC = c00 * c11 - c01 * c01;
+        double T[6];
+        {
+            // sqrt of SPD 2x2: S = (C + sqrt(det) I) / sqrt(tr + 2 sqrt(det)); T = F S^-1
+            const double sd = sqrt(detC > 0.0 ? detC : 0.0);
+            const double tr = c00 + c11;
+            const double den = sqrt(tr + 2.0 * sd);
+            const double s00 = (c00 + sd) / den, s01 = c01 / den, s11 = (c11 + sd) / den;
+            const double ds = s00 * s11 - s01 * s01;
+            const double i00 = s11 / ds, i01 = -s01 / ds, i11 = s00 / ds;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
-    if (b.par[(size_t)3 * n + e] != 0.0) {
-        const double lmin = b.par[(size_t)1 * n + e], lmax = b.par[(size_t)2 * n + e];
-        const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
-        const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
-        const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
-        if (l0 < lmin) { const double sc = lmin / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
-        if (l1 < lmin) { const double sc = lmin / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
-        if (l0 > lmax) { const double sc = lmax / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
-        if (l1 > lmax) { const double sc = lmax / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+            for (int j = 0; j < 3; ++j) { T[j] = d[j] * i00 + d[3 + j] * i01; T[3 + j] = d[j] * i01 + d[3 + j] * i11; }
+        }
+        const double k = b.kblend[e], w2 = b.w2[e];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
+        if (b.par[(size_t)3 * n + e] != 0.0) {
+            const double lmin = b.par[(size_t)1 * n + e], lmax = b.par[(size_t)2 * n + e];
+            const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
+            const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
+            const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
+            if (l0 < lmin) { const double sc = lmin / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+            if (l1 < lmin) { const double sc = lmin / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+            if (l0 > lmax) { const double sc = lmax / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+            if (l1 > lmax) { const double sc = lmax / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+        }
+    } else if (MODE == 1) {
+        double p[6];
+        project_triarea_p(d, (int)b.par[(size_t)1 * n + e], b.par[(size_t)2 * n + e], b.par[(size_t)3 * n + e], p);
+        const double k = b.kblend[e], w2 = b.w2[e];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zi[i] = (k * p[i] + w2 * d[i]) / (w2 + k);
+    } else {
+        double hs = b.state[(size_t)3 * n + e];
+        int it = 0;
+        project_fung(d, b.par[e], hs, it, zi);
+        b.state[(size_t)3 * n + e] = hs;
+        b.n_iters[e] = it;
     }
     double q[6];
 #pragma unroll

@@ -595,4 +595,205 @@ template <bool VOLUME> ADMM_HD Mat3 project_tet_p(const Mat3 &d, double limit_mi
     return recompose(U, n0, n1, n2, V);
 }
 
+// ---- Eigen::JacobiSVD<Matrix<double,3,2>>(F, ComputeFullU | ComputeFullV) ----------------------
+// Default ColPivHouseholderQR preconditioner (EIG/SVD/JacobiSVD.h:153-194, EIG/QR/ColPivHouseholderQR.h:428-497,
+// EIG/Householder/Householder.h:65-140), then the two-sided Jacobi on the 2x2 R factor with the
+// steps of svd3 above.  F col-major 3x2; only the first two columns of U (what the triangle
+// forces use) and V (2x2, col-major) are returned.  Follows oracle/admm_oracle.c orc_svd32.
+ADMM_HD void svd32(const double F[6], double U2[6], double &s0, double &s1, double V[4]) {
+    double scale = fabs(F[0]);
+#pragma unroll
+    for (int i = 1; i < 6; ++i) scale = smax(scale, fabs(F[i]));
+    if (scale == 0.0) scale = 1.0;
+    double a0 = F[0] / scale, a1 = F[1] / scale, a2 = F[2] / scale;   // column 0 of the QR work matrix
+    double b0 = F[3] / scale, b1 = F[4] / scale, b2 = F[5] / scale;   // column 1
+    const double n0 = a0 * a0 + (a1 * a1 + a2 * a2), n1 = b0 * b0 + (b1 * b1 + b2 * b2);
+    const bool swapped = n1 > n0;                                      // column pivoting: larger column first
+    if (swapped) { double t; t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; t = a2; a2 = b2; b2 = t; }
+    // Householder 0 on (a0, a1, a2)
+    double tau0, e01, e02, beta0;
+    {
+        const double tailSq = a1 * a1 + a2 * a2;
+        if (tailSq == 0.0) { tau0 = 0.0; beta0 = a0; e01 = 0.0; e02 = 0.0; }
+        else {
+            beta0 = sqrt(a0 * a0 + tailSq);
+            if (a0 >= 0.0) beta0 = -beta0;
+            e01 = a1 / (a0 - beta0); e02 = a2 / (a0 - beta0);
+            tau0 = (beta0 - a0) / beta0;
+        }
+        double tmp = e01 * b1 + e02 * b2;
+        tmp += b0;
+        b0 -= tau0 * tmp; b1 -= tau0 * e01 * tmp; b2 -= tau0 * e02 * tmp;
+    }
+    // Householder 1 on (b1, b2)
+    double tau1, e12, beta1;
+    {
+        const double tailSq = b2 * b2;
+        if (tailSq == 0.0) { tau1 = 0.0; beta1 = b1; e12 = 0.0; }
+        else {
+            beta1 = sqrt(b1 * b1 + tailSq);
+            if (b1 >= 0.0) beta1 = -beta1;
+            e12 = b2 / (b1 - beta1);
+            tau1 = (beta1 - b1) / beta1;
+        }
+    }
+    // work matrix = R (2x2 upper triangular): w00 w01 / 0 w11
+    double w00 = beta0, w10 = 0.0, w01 = b0, w11 = beta1;
+    // full Q = H0 H1 applied to the identity, right to left (HouseholderSequence::evalTo)
+    double q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // col-major 3x3
+    // k = 1: bottom-right 2x2 block, essential (e12)
+#pragma unroll
+    for (int c = 1; c < 3; ++c) {
+        double *col = &q[1 + 3 * c];
+        double tmp = e12 * col[1];
+        tmp += col[0];
+        col[0] -= tau1 * tmp;
+        col[1] -= tau1 * e12 * tmp;
+    }
+    // k = 0: whole matrix, essential (e01, e02)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double *col = &q[3 * c];
+        double tmp = e01 * col[1];
+        tmp = tmp + e02 * col[2];
+        tmp += col[0];
+        col[0] -= tau0 * tmp;
+        col[1] -= tau0 * e01 * tmp;
+        col[2] -= tau0 * e02 * tmp;
+    }
+    // V = the column permutation
+    double v00 = 1.0, v10 = 0.0, v01 = 0.0, v11 = 1.0;
+    if (swapped) { v00 = 0.0; v10 = 1.0; v01 = 1.0; v11 = 0.0; }
+    // two-sided Jacobi on W, pair (p, q) = (1, 0); rotations act on columns 0,1 of Q and V
+    const double precision = 2.0 * DBL_EPSILON;
+    const double considerAsZero = 2.0 * 4.9406564584124654e-324;
+    bool finished = false;
+    while (!finished) {
+        finished = true;
+        const double threshold = smax(considerAsZero, precision * smax(fabs(w11), fabs(w00)));
+        if (fabs(w10) > threshold || fabs(w01) > threshold) {
+            finished = false;
+            // real_2x2_jacobi_svd on [[w11, w10], [w01, w00]] (rows/cols p=1, q=0)
+            double m00 = w11, m01 = w10, m10 = w01, m11 = w00;
+            double c1, s1r;
+            const double t = m00 + m11, d = m10 - m01;
+            if (t == 0.0) { c1 = 0.0; s1r = d > 0.0 ? 1.0 : -1.0; }
+            else {
+                const double t2d2 = eig_hypot(t, d);
+                c1 = fabs(t) / t2d2;
+                s1r = d / t2d2;
+                if (t < 0.0) s1r = -s1r;
+            }
+            if (!(c1 == 1.0 && s1r == 0.0)) { rot2(m00, m10, c1, s1r); rot2(m01, m11, c1, s1r); }
+            double rc, rs;
+            if (m01 == 0.0) { rc = 1.0; rs = 0.0; }
+            else {
+                const double tau = (m00 - m11) / (2.0 * fabs(m01));
+                const double w = sqrt(tau * tau + 1.0);
+                const double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+                const double sign_t = tt > 0.0 ? 1.0 : -1.0;
+                const double n = 1.0 / sqrt(tt * tt + 1.0);
+                rs = -sign_t * unit_sign(m01) * fabs(tt) * n;
+                rc = n;
+            }
+            const double os = -rs;
+            const double lc = c1 * rc - s1r * os, ls = c1 * os + s1r * rc;
+            // W.applyOnTheLeft(p, q, j_left): rows p=1 and q=0
+            if (!(lc == 1.0 && ls == 0.0)) {
+                rot2(w10, w00, lc, ls); rot2(w11, w01, lc, ls);
+                // U.applyOnTheRight(p, q, j_left^T): columns 1 and 0 of Q
+#pragma unroll
+                for (int r = 0; r < 3; ++r) rot2(q[r + 3], q[r], lc, ls);
+            }
+            // W.applyOnTheRight(p, q, j_right), V likewise: columns 1 and 0
+            if (!(rc == 1.0 && -rs == 0.0)) {
+                rot2(w01, w00, rc, -rs); rot2(w11, w10, rc, -rs);
+                rot2(v01, v00, rc, -rs); rot2(v11, v10, rc, -rs);
+            }
+        }
+    }
+    double sa = fabs(w00), sb = fabs(w11);
+    if (sa != 0.0) { const double f = unit_sign(w00); q[0] *= f; q[1] *= f; q[2] *= f; }
+    if (sb != 0.0) { const double f = unit_sign(w11); q[3] *= f; q[4] *= f; q[5] *= f; }
+    if (sb > sa) {   // descending, first maximum wins; a zero maximum leaves everything in place
+        double t = sa; sa = sb; sb = t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { t = q[r]; q[r] = q[r + 3]; q[r + 3] = t; }
+        t = v00; v00 = v01; v01 = t; t = v10; v10 = v11; v11 = t;
+    }
+    s0 = sa * scale; s1 = sb * scale;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) U2[i] = q[i];
+    V[0] = v00; V[1] = v10; V[2] = v01; V[3] = v11;
+}
+
+// U(:, :2) diag(s) V^T for the 3x2 case: ((U Diag) V^T), Diag's zero products add nothing
+ADMM_HD void recompose32(const double U2[6], double s0, double s1, const double V[4], double out[6]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i + 3 * j] = (U2[i] * s0) * V[j] + (U2[i + 3] * s1) * V[j + 2];
+}
+
+// ---- TriArea::project's projection p (CORE/TriangleForce.cpp:251-283), d = Dx_i + u_i ----------
+ADMM_HD void project_triarea_p(const double d[6], int iters, double lmin, double lmax, double p[6]) {
+    double U2[6], V[4], sv0, sv1;
+    svd32(d, U2, sv0, sv1, V);
+    double S0 = sv0, S1 = sv1, d0 = 0.0, d1 = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        const double v = S0 * S1;
+        double c = (v < lmax ? v : lmax);
+        c = (c > lmin ? c : lmin);
+        const double f = v - c;
+        const double g0 = S1, g1 = S0;
+        const double q = -((f - (g0 * d0 + g1 * d1)) / (g0 * g0 + g1 * g1));
+        d0 = q * g0; d1 = q * g1;
+        S0 = sv0 + d0; S1 = sv1 + d1;
+    }
+    recompose32(U2, S0, S1, V, p);
+}
+
+// ---- FungProx (CORE/TriangleForce.cpp:120-169): two variables riding in V3 with c == 0 ----------
+// (every reduction in the L-BFGS / line search is (a + b) + c, so the zero third component leaves
+// the arithmetic of the 2-variable solver untouched)
+struct FungProx {
+    double mu, k;
+    V3 s0;
+    ADMM_HD double value(const V3 &x) const {
+        if (x.a <= 0.0 || x.b <= 0.0) return kFltMax;
+        const double b = 1.0;
+        const double s3 = 1.0 / (x.a * x.b);
+        const double I_1 = x.a * x.a + x.b * x.b + s3 * s3;
+        const double t1 = mu / (b * 2.0);
+        const double t2 = exp(b * (I_1 - 3.0)) - 1.0;
+        const double r0 = isfinite(t2) ? (t1 * t2) : kFltMax;
+        const double da = x.a - s0.a, db = x.b - s0.b;
+        const double r2 = (k * 0.5) * (da * da + db * db);
+        return (r0 + r2);
+    }
+    ADMM_HD V3 gradient(const V3 &x) const {
+        V3 g; g.c = 0.0;
+        const double minval = 1.17549435082228750797e-38; // FLT_MIN
+        if (fabs(x.a) < minval || fabs(x.b) < minval) { g.a = g.b = 1.0 * kFltMax; return g; }
+        const double b = 1.0;
+        const double sig3 = 1.0 / (x.a * x.b);
+        const double I_1 = (x.a * x.a + x.b * x.b + sig3 * sig3);
+        const double t1 = 0.5 * mu * exp(b * (I_1 - 3.0));
+        const double t20 = k * (x.a - s0.a), t21 = k * (x.b - s0.b);
+        g.a = t1 * (2.0 * x.a - 2.0 / (x.a * x.a * x.a * x.b * x.b)) + t20;
+        g.b = t1 * (2.0 * x.b - 2.0 / (x.b * x.b * x.b * x.a * x.a)) + t21;
+        return g;
+    }
+};
+
+// ---- FungTriangle::project (CORE/TriangleForce.cpp:227-249): z = U diag(argmin prox) V^T ---------
+ADMM_HD void project_fung(const double d[6], double mu, double &hess, int &n_iters, double z[6]) {
+    double U2[6], V[4], sv0, sv1;
+    svd32(d, U2, sv0, sv1, V);
+    FungProx P; P.mu = mu; P.k = mu; P.s0.a = sv0; P.s0.b = sv1; P.s0.c = 0.0;
+    V3 x2; x2.a = sv0; x2.b = sv1; x2.c = 0.0;
+    n_iters = lbfgs_minimize<10>(P, x2, 10, 1e-6, hess);
+    recompose32(U2, x2.a, x2.b, V, z);
+}
+
 } // namespace admm_dev

@@ -88,6 +88,27 @@ public:
     bool strain_limiting;
 };
 
+// TriangleForce.hpp:126-133: area-preserving triangle; inherits the strain triangle's rest data and weight
+class TriArea : public LimitedTriangleStrain {
+public:
+    TriArea(int id0_, int id1_, int id2_, double stiffness_, int iters_, double limit_min_, double limit_max_)
+        : LimitedTriangleStrain(id0_, id1_, id2_, stiffness_, limit_min_, limit_max_), iters(iters_) {}
+    int kind() const { return ADMM_KIND_TRI_AREA; }
+    void describe(int *id, double *p) const { id[0] = id0; id[1] = id1; id[2] = id2; p[0] = stiffness; p[1] = iters; p[2] = limit_min; p[3] = limit_max; }
+    int iters;
+};
+
+// TriangleForce.hpp:106-124: Fung skin membrane, prox by L-BFGS (2 variables, maxIter 10, gradTol 1e-6)
+class FungTriangle : public Force {
+public:
+    FungTriangle(int id0_, int id1_, int id2_, double mu_, double limit_min_, double limit_max_)
+        : id0(id0_), id1(id1_), id2(id2_), mu(mu_), limit_min(limit_min_), limit_max(limit_max_), area(0) {}
+    int kind() const { return ADMM_KIND_TRI_FUNG; }
+    void describe(int *id, double *p) const { id[0] = id0; id[1] = id1; id[2] = id2; p[0] = mu; p[1] = limit_min; p[2] = limit_max; }
+    int id0, id1, id2;
+    double mu, limit_min, limit_max, area;
+};
+
 class BendForce : public Force {
 public:
     BendForce(int i0, int i1, int i2, int i3, double stiffness_) : stiffness(stiffness_) { idx[0] = i0; idx[1] = i1; idx[2] = i2; idx[3] = i3; weight = std::sqrt(stiffness); }

@@ -80,9 +80,10 @@ int admm_hip_add_gravity(admm_hip_ctx *ctx, double gx, double gy, double gz);
  * new WindForce(tris) (ExplicitForce.hpp:51-71).  type ADMM_EXPLICIT_CONST: idx = node ids
  * (n_idx = 0: all nodes); ADMM_EXPLICIT_WIND: idx = [n_idx][3] triangle node ids, dir = wind
  * direction.  Explicit forces are applied in the order they were added.  The reference's
- * wind loop scatters with an omp critical in thread-dependent order and reads velocities
- * other threads are updating; here all triangle forces are evaluated on the velocity field
- * left by the previous explicit force and summed per node in triangle order.            */
+ * wind loop is an omp-parallel loop that reads velocities other threads are updating and
+ * scatters under an omp critical, so its result depends on the thread schedule; this library
+ * reproduces the loop run serially (OMP_NUM_THREADS=1): triangle i sees the increments of the
+ * triangles before it, every node is incremented in triangle order (deterministic).        */
 int admm_hip_add_explicit(admm_hip_ctx *ctx, int type, const double *dir, int n_idx, const int32_t *idx, int *which);
 /* replaces: CollisionForce::collisionShapes (CollisionForce.hpp:39): the shape table used by
  * every ADMM_KIND_COLLISION batch, tested in order like CollisionForce::handleCollisions

@@ -17,6 +17,8 @@
  *   TRI_STRAIN    LimitedTriangleStrain        TriangleForce.cpp:29-113  3    6
  *   BEND          BendForce                    BendForce.cpp:26-161      4    9
  *   COLLISION     CollisionForce (one element per node)  CollisionForce.cpp:27-70  1    3
+ *   TRI_AREA      TriArea                      TriangleForce.cpp:257-295 3    6
+ *   TRI_FUNG      FungTriangle                 TriangleForce.cpp:120-249 3    6
  *
  * "rows" are the compact rows of D/u/z per element.  (The reference gives
  * every tet 36 rows of which 27 are structurally zero -- TetForce.cpp:61 vs
@@ -39,17 +41,19 @@ enum admm_kind {
     ADMM_KIND_TRI_STRAIN = 6,
     ADMM_KIND_BEND       = 7,
     ADMM_KIND_COLLISION  = 8,
-    ADMM_KIND_COUNT      = 9
+    ADMM_KIND_TRI_AREA   = 9,
+    ADMM_KIND_TRI_FUNG   = 10,
+    ADMM_KIND_COUNT      = 11
 };
 
 /* nodes per element */
-static const int ADMM_KIND_NODES[ADMM_KIND_COUNT]  = { 1, 2, 4, 4, 4, 4, 3, 4, 1 };
+static const int ADMM_KIND_NODES[ADMM_KIND_COUNT]  = { 1, 2, 4, 4, 4, 4, 3, 4, 1, 3, 3 };
 /* compact D rows per element */
-static const int ADMM_KIND_ROWS[ADMM_KIND_COUNT]   = { 3, 3, 9, 9, 9, 9, 6, 9, 3 };
+static const int ADMM_KIND_ROWS[ADMM_KIND_COUNT]   = { 3, 3, 9, 9, 9, 9, 6, 9, 3, 6, 6 };
 /* doubles of constructor parameters per element (see admm_hip_add_batch) */
-static const int ADMM_KIND_PARAMS[ADMM_KIND_COUNT] = { 2, 1, 1, 3, 3, 3, 4, 1, 1 };
+static const int ADMM_KIND_PARAMS[ADMM_KIND_COUNT] = { 2, 1, 1, 3, 3, 3, 4, 1, 1, 4, 3 };
 /* doubles of persistent warm-start state per element */
-static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0, 0 };
+static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0, 0, 0, 4 };
 
 /*
  * params layout per kind (doubles, element-major [n_elems][ADMM_KIND_PARAMS]):
@@ -64,7 +68,10 @@ static const int ADMM_KIND_STATE[ADMM_KIND_COUNT]  = { 0, 0, 0, 0, 4, 4, 0, 0, 0
  *   COLLISION   { use_weight }   (CollisionForce.hpp:33: default 32); the reference's single
  *               CollisionForce over all nodes is one batch with one element per node, in node
  *               order; the shapes are set with admm_hip_set_collision_shapes
+ *   TRI_AREA    { stiffness, iters, limit_min, limit_max }   (TriangleForce.hpp:126-133)
+ *   TRI_FUNG    { mu, limit_min, limit_max }                  (TriangleForce.hpp:106-124; L-BFGS maxIter 10, gradTol 1e-6)
  * state layout (TET_NH/STVK): { last_prox_result[3], init_hess }  (TetForce.hpp:146, meta.h:33)
+ *              (TRI_FUNG):    { -, -, -, init_hess }  the solver's persisted Hessian guess; no warm start
  */
 
 /* analytic collision shapes (deps/admm-elastic-sca/src/collision/), tested in list order */

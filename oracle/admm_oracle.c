@@ -302,9 +302,41 @@ static double stvk_energy(const prox3 *p, const double *s) {
     double dd = st[0] * st[0] + (st[1] * st[1] + st[2] * st[2]); /* trace of a fixed 3x3 */
     return (p->mu * dd + (p->lambda * 0.5 * st_tr2));
 }
+/*
+ * FungProx (CORE/TriangleForce.cpp:120-169): a problem in TWO variables.  It runs through the
+ * same 3-variable L-BFGS / line-search code with x[2] == s[2] == g[2] == 0: every reduction
+ * there is the dynamic-size (a0 + a1) + a2, and adding a zero changes nothing, so the numbers
+ * are those of the 2-variable solver.
+ */
+static double fung_value(const prox3 *p, const double *x) {
+    if (x[0] <= 0.0 || x[1] <= 0.0) return FLTMAX;
+    const double b = 1.0;
+    double s3 = 1.0 / (x[0] * x[1]);
+    double I_1 = x[0] * x[0] + x[1] * x[1] + s3 * s3;
+    double t1 = p->mu / (b * 2.0);
+    double t2 = exp(b * (I_1 - 3.0)) - 1.0;
+    double r0;
+    if (!isfinite(t2)) r0 = FLTMAX; else r0 = (t1 * t2);
+    double d0 = x[0] - p->s0[0], d1 = x[1] - p->s0[1];
+    double r2 = (p->k * 0.5) * (d0 * d0 + d1 * d1);
+    return (r0 + r2);
+}
+static void fung_gradient(const prox3 *p, const double *x, double *g) {
+    const double minval = (double)FLT_MIN, b = 1.0;
+    g[2] = 0.0;
+    if (fabs(x[0]) < minval || fabs(x[1]) < minval) { g[0] = g[1] = 1.0 * FLTMAX; return; }
+    double sig3 = 1.0 / (x[0] * x[1]);
+    double I_1 = (x[0] * x[0] + x[1] * x[1] + sig3 * sig3);
+    double t1 = 0.5 * p->mu * exp(b * (I_1 - 3.0));
+    double t20 = p->k * (x[0] - p->s0[0]), t21 = p->k * (x[1] - p->s0[1]);
+    g[0] = t1 * (2.0 * x[0] - 2.0 / (x[0] * x[0] * x[0] * x[1] * x[1])) + t20;
+    g[1] = t1 * (2.0 * x[1] - 2.0 / (x[1] * x[1] * x[1] * x[0] * x[0])) + t21;
+}
+
 /* NHProx::value :228-233 / StVKProx::value :281-287 */
 static double prox_value(prox3 *p, const double *x) {
     p->n_fev++;
+    if (p->type == 2) return fung_value(p, x);
     if (x[0] < 0.0 || x[1] < 0.0 || x[2] < 0.0) return FLTMAX;
     double d[3] = { x[0] - p->s0[0], x[1] - p->s0[1], x[2] - p->s0[2] };
     if (p->type == 0) {
@@ -319,6 +351,7 @@ static double prox_value(prox3 *p, const double *x) {
 }
 /* NHProx::gradient :235-243 / StVKProx::gradient :289-297 */
 static void prox_gradient(prox3 *p, const double *x, double *g) {
+    if (p->type == 2) { fung_gradient(p, x, g); return; }
     if (p->type == 0) {
         double detSigma = x[0] * x[1] * x[2];
         if (detSigma <= 0.0) { g[0] = g[1] = g[2] = 1.0 * FLTMAX; return; }
@@ -589,6 +622,9 @@ void orc_force_construct(orc_force *f, int kind, const int *idx, const double *p
     case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK: /* CORE/TetForce.hpp:127-128; OPT/meta.h:33 */
         f->state[0] = f->state[1] = f->state[2] = 1.0; f->state[3] = 1.0;
         break;
+    case ADMM_KIND_TRI_FUNG: /* solver settings init_hess, OPT/meta.h:33 */
+        f->state[3] = 1.0;
+        break;
     default: break;
     }
 }
@@ -686,9 +722,13 @@ void orc_force_initialize(orc_force *f, const double *x) {
         f->weight = sqrtf(stiff) * sqrtf(f->measure);
         break;
     }
-    case ADMM_KIND_TRI_STRAIN:
+    case ADMM_KIND_TRI_STRAIN: case ADMM_KIND_TRI_AREA: /* TriArea inherits LimitedTriangleStrain::initialize */
         init_tri_force(f->idx, x, &f->measure, f->B);
         f->weight = sqrtf(f->params[0]) * sqrtf(f->measure);
+        break;
+    case ADMM_KIND_TRI_FUNG: /* FungTriangle::initialize, CORE/TriangleForce.cpp:171-210: double sqrt, k = mu */
+        init_tri_force(f->idx, x, &f->measure, f->B);
+        f->weight = sqrt(f->params[0]) * sqrt(f->measure);
         break;
     case ADMM_KIND_BEND:
         f->weight = sqrt(f->params[0]);
@@ -782,6 +822,58 @@ static void project_tri(orc_force *f, const double *Dx, double *u, double *z) {
     for (int i = 0; i < 6; ++i) { u[i] = u[i] + (Dx[i] - zi[i]); z[i] = zi[i]; }
 }
 
+/* U(:, :2) * diag(s) * V^T for a 3x2 F: ((U*Diag)*V^T), the zero products of Diag add nothing */
+static void recompose32(const double *U, const double *s, const double *V, double *out) {
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 3; ++i)
+        out[i + 3 * j] = (U[i] * s[0]) * V[j] + (U[i + 3] * s[1]) * V[j + 2];
+}
+
+/* TriArea::project, CORE/TriangleForce.cpp:251-295 */
+static void project_triarea(orc_force *f, const double *Dx, double *u, double *z) {
+    double d[6];
+    for (int i = 0; i < 6; ++i) d[i] = Dx[i] + u[i];
+    double U[9], sv[2], V[4];
+    orc_svd32(d, U, sv, V);
+    double S[2] = { sv[0], sv[1] }, dd[2] = { 0.0, 0.0 };
+    const int iters = (int)f->params[1];
+    const double lmin = f->params[2], lmax = f->params[3];
+    for (int i = 0; i < iters; ++i) {
+        double v = S[0] * S[1];
+        double c = (v < lmax ? v : lmax);
+        c = (c > lmin ? c : lmin);
+        double fv = v - c;
+        double g[2] = { S[1], S[0] };
+        double q = -((fv - (g[0] * dd[0] + g[1] * dd[1])) / (g[0] * g[0] + g[1] * g[1]));
+        dd[0] = q * g[0]; dd[1] = q * g[1];
+        S[0] = sv[0] + dd[0]; S[1] = sv[1] + dd[1];
+    }
+    double p[6];
+    recompose32(U, S, V, p);
+    double k = f->params[0] * f->measure;
+    double w2 = f->weight * f->weight;
+    for (int i = 0; i < 6; ++i) {
+        double zi = (k * p[i] + w2 * d[i]) / (w2 + k);
+        u[i] = u[i] + (Dx[i] - zi); z[i] = zi;
+    }
+}
+
+/* FungTriangle::project, CORE/TriangleForce.cpp:227-249 */
+static void project_fung(orc_force *f, const double *Dx, double *u, double *z) {
+    double d[6];
+    for (int i = 0; i < 6; ++i) d[i] = Dx[i] + u[i];
+    double U[9], sv[2], V[4];
+    orc_svd32(d, U, sv, V);
+    prox3 P;
+    P.type = 2; P.mu = f->params[0]; P.lambda = 0.0; P.k = f->params[0];
+    P.s0[0] = sv[0]; P.s0[1] = sv[1]; P.s0[2] = 0.0; P.n_fev = 0;
+    double x2[3] = { sv[0], sv[1], 0.0 };
+    f->n_iters = lbfgs_minimize(&P, x2, 10, 1e-6, &f->state[3]);
+    f->n_fev = P.n_fev;
+    double zi[6];
+    recompose32(U, x2, V, zi);
+    for (int i = 0; i < 6; ++i) { u[i] = u[i] + (Dx[i] - zi[i]); z[i] = zi[i]; }
+}
+
 /* BendForce::project + computeUsingProjection, CORE/BendForce.cpp:131-161 */
 static void project_bend(orc_force *f, const double *Dx, double *u, double *z) {
     double d[9], p[9];
@@ -867,6 +959,8 @@ void orc_force_project(orc_force *f, double dt, const double *Dx, double *u, dou
     case ADMM_KIND_TET_LINEAR: case ADMM_KIND_TET_VOLUME: project_tet_blend(f, Dx, u, z); break;
     case ADMM_KIND_TET_NH: case ADMM_KIND_TET_STVK: project_hyper(f, Dx, u, z); break;
     case ADMM_KIND_TRI_STRAIN: project_tri(f, Dx, u, z); break;
+    case ADMM_KIND_TRI_AREA: project_triarea(f, Dx, u, z); break;
+    case ADMM_KIND_TRI_FUNG: project_fung(f, Dx, u, z); break;
     case ADMM_KIND_BEND: project_bend(f, Dx, u, z); break;
     }
 }
@@ -1018,7 +1112,7 @@ static void get_selector(orc_system *s, orc_force *f) {
         else for (int i = 0; i < 9; ++i) push_w(s, f->weight);
         break;
     }
-    case ADMM_KIND_TRI_STRAIN: /* CORE/TriangleForce.cpp:66-75 */
+    case ADMM_KIND_TRI_STRAIN: case ADMM_KIND_TRI_AREA: case ADMM_KIND_TRI_FUNG: /* CORE/TriangleForce.cpp:66-75, 213-223 */
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
             push_trip(s, i + g, 3 * f->idx[j] + i, f->B[j + 3 * 0]);
             push_trip(s, 3 + i + g, 3 * f->idx[j] + i, f->B[j + 3 * 1]);

@@ -62,6 +62,8 @@ std::shared_ptr<Force> make_force(RefSystem *sys, int kind, const int *idx, cons
     case ADMM_KIND_TET_STVK: return std::shared_ptr<Force>(new HyperElasticTet(idx[0], idx[1], idx[2], idx[3], p[0], p[1], (int)p[2], "stvk"));
     case ADMM_KIND_TRI_STRAIN: return std::shared_ptr<Force>(new LimitedTriangleStrain(idx[0], idx[1], idx[2], p[0], p[1], p[2], p[3] != 0.0));
     case ADMM_KIND_BEND: return std::shared_ptr<Force>(new BendForce(idx[0], idx[1], idx[2], idx[3], p[0]));
+    case ADMM_KIND_TRI_AREA: return std::shared_ptr<Force>(new TriArea(idx[0], idx[1], idx[2], p[0], (int)p[1], p[2], p[3]));
+    case ADMM_KIND_TRI_FUNG: return std::shared_ptr<Force>(new FungTriangle(idx[0], idx[1], idx[2], p[0], p[1], p[2]));
     }
     return std::shared_ptr<Force>();
 }
@@ -184,6 +186,9 @@ long ref_L_nnz(void *h) { return (long)((RefSystem *)h)->LDLT().matrixL().nested
 
 // HyperElasticTet warm-start state (TetForce.hpp:146; cppoptlib meta.h:33; isolver.h:20)
 int ref_get_hyper_state(void *h, int i, double *state4) {
+    if (FungTriangle *g = dynamic_cast<FungTriangle *>(((RefSystem *)h)->forces[i].get())) {
+        state4[0] = state4[1] = state4[2] = 0.0; state4[3] = g->solver->settings_.init_hess; return g->solver->n_iters;
+    }
     HyperElasticTet *f = dynamic_cast<HyperElasticTet *>(((RefSystem *)h)->forces[i].get());
     if (!f) return -1;
     for (int j = 0; j < 3; ++j) state4[j] = f->last_prox_result[j];
@@ -231,11 +236,14 @@ int ref_project_single(int kind, const double *x_rest, const double *params, dou
         else if (TetVolume *t = dynamic_cast<TetVolume *>(f.get())) { for (int i = 0; i < 12; ++i) init_out[k++] = t->B.data()[i]; init_out[k++] = t->rest_volume; }
         else if (HyperElasticTet *t = dynamic_cast<HyperElasticTet *>(f.get())) { for (int i = 0; i < 12; ++i) init_out[k++] = t->B.data()[i]; init_out[k++] = t->volume; }
         else if (LimitedTriangleStrain *t = dynamic_cast<LimitedTriangleStrain *>(f.get())) { for (int i = 0; i < 6; ++i) init_out[k++] = t->B.data()[i]; init_out[k++] = t->area; }
+        else if (FungTriangle *t = dynamic_cast<FungTriangle *>(f.get())) { for (int i = 0; i < 6; ++i) init_out[k++] = t->B.data()[i]; init_out[k++] = t->area; }
         else if (BendForce *t = dynamic_cast<BendForce *>(f.get())) { for (int i = 0; i < 4; ++i) init_out[k++] = t->alpha[i]; }
         else if (Spring *t = dynamic_cast<Spring *>(f.get())) { init_out[k++] = t->rest_length; }
     }
     HyperElasticTet *he = dynamic_cast<HyperElasticTet *>(f.get());
+    FungTriangle *fu = dynamic_cast<FungTriangle *>(f.get());
     if (he && state) { for (int j = 0; j < 3; ++j) he->last_prox_result[j] = state[j]; he->solver->settings_.init_hess = state[3]; }
+    if (fu && state) fu->solver->settings_.init_hess = state[3];
     const int R = (int)w.size(); // 36 for tets (TetForce.cpp:313-317), else rows
     VectorXd Dxv = VectorXd::Zero(R), uv = VectorXd::Zero(R), zv = VectorXd::Zero(R);
     for (int r = 0; r < rows; ++r) uv[r] = u[r];
@@ -244,9 +252,11 @@ int ref_project_single(int kind, const double *x_rest, const double *params, dou
         f->project(dt, Dxv, uv, zv);
         for (int r = 0; r < rows; ++r) { z_out[(size_t)c * rows + r] = zv[r]; u_out[(size_t)c * rows + r] = uv[r]; }
         if (he && n_iters_out) n_iters_out[c] = he->solver->n_iters;
+        if (fu && n_iters_out) n_iters_out[c] = fu->solver->n_iters;
     }
     for (int r = 0; r < rows; ++r) u[r] = uv[r];
     if (he && state) { for (int j = 0; j < 3; ++j) state[j] = he->last_prox_result[j]; state[3] = he->solver->settings_.init_hess; }
+    if (fu && state) state[3] = fu->solver->settings_.init_hess;
     return 0;
 }
 

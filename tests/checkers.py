@@ -15,10 +15,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8)
-KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1]
-KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3]
-KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1]
+KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8, TRI_AREA=9, TRI_FUNG=10)
+KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1, 3, 3]
+KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3, 6, 6]
+KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1, 4, 3]
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -393,7 +393,7 @@ class Oracle(_Sys):
         init[0] = f.weight
         if kind in (2, 3, 4, 5):
             init[1:13] = list(f.B); init[13] = f.measure
-        elif kind == 6:
+        elif kind in (6, 9, 10):
             init[1:7] = list(f.B)[:6]; init[7] = f.measure
         elif kind == 7:
             init[1:5] = list(f.alpha)

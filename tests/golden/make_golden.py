@@ -67,11 +67,14 @@ def gen_Dx(rng, kind, ncalls, amp):
 PROJECT_CASES = {
     "TET_NH": [1e5, 1e5, 5], "TET_STVK": [100.0, 100.0, 5], "TET_LINEAR": [1e3], "TET_VOLUME": [100.0, 0.9, 1.1],
     "TRI_STRAIN": [100.0, 0.95, 1.05, 1], "BEND": [20.0], "SPRING": [50.0], "ANCHOR": [-1.0, 1.0],
+    "TRI_AREA": [100.0, 4, 0.9, 1.1], "TRI_FUNG": [50.0, 0.5, 2.0],
 }
 
 
-def make_projects():
+def make_projects(only=None):
     for name, params in PROJECT_CASES.items():
+        if only and name not in only:
+            continue
         kind = KIND[name]
         rng = np.random.default_rng(1000 + kind)
         N, Cc = 256, 4
@@ -87,7 +90,7 @@ def make_projects():
             X[e] = x; DX[e] = Dx; U0[e] = u0; Z[e] = r["z"]; U[e] = r["u"]; ST[e] = r["state"]; IT[e] = r["n_iters"]; INIT[e] = r["init"]
         np.savez_compressed(os.path.join(HERE, "project_%s.npz" % name), kind=kind, params=np.array(params, dtype=np.float64), x_rest=X, Dx=DX, u0=U0,
                             z=Z, u=U, state=ST, n_iters=IT, init=INIT)
-        print("project", name, "iters hist", np.bincount(IT.ravel())[:12] if name in ("TET_NH", "TET_STVK") else "")
+        print("project", name, "iters hist", np.bincount(IT.ravel())[:12] if name in ("TET_NH", "TET_STVK", "TRI_FUNG") else "", "non-finite z:", int((~np.isfinite(Z)).any(axis=(1, 2)).sum()))
 
 
 def make_known_answers():
@@ -260,6 +263,36 @@ def make_cloth():
     print("cloth: nodes", n, "tris", tris.shape[0], "hinges", hinges.shape[0])
 
 
+def make_skin():
+    """Two small membranes for the triangle kinds no sample instantiates:
+    TriArea (area preservation) + Bend, and FungTriangle skin, both pinned on one edge under gravity."""
+    w, l = 8, 6
+    x, tris = meshgen.sym_plane(w, l, size=0.4)
+    x = x.astype(np.float32).astype(np.float64)
+    hinges = meshgen.bend_hinges(tris)
+    n = x.shape[0]
+    anchors = np.arange(0, w + 1, dtype=np.int32)
+    for name, kind, par, extra, frames in (("triarea", "TRI_AREA", [100.0, 4, 0.95, 1.05], True, 4), ("fung", "TRI_FUNG", [40.0, 0.5, 2.0], False, 3)):
+        def build():
+            r = Ref(); r.settings(0.02, 15)
+            r.add_nodes(x.ravel(), np.full(3 * n, 0.2 / n))
+            r.add_forces(KIND[kind], tris, par)
+            if extra:
+                r.add_forces(KIND["BEND"], hinges, [5.0])
+            r.add_forces(KIND["ANCHOR"], anchors, [-1.0, 1.0])
+            r.add_gravity([0, -9.8, 0])
+            assert r.initialize()
+            return r
+        r = build()
+        X = []
+        for _ in range(frames):
+            r.step(); X.append(r.x.copy())
+        env = envelope(build, frames)
+        np.savez_compressed(os.path.join(HERE, "traj_skin_%s.npz" % name), x=x, tris=tris, hinges=hinges, anchors=anchors, mass=0.2 / n, kind=KIND[kind], params=np.array(par),
+                            with_bend=extra, k_bend=5.0, dt=0.02, iters=15, x_frames=np.array(X), ulp_sensitivity=env, global_idx=r.global_idx(), wdiag_head=r.wdiag[:12])
+        print("skin", name, "finite", np.isfinite(np.array(X)).all(), "sag", np.array(X)[-1].reshape(-1, 3)[:, 1].min(), "envelope", env)
+
+
 def make_collision():
     """plinkopony-like (samples/plinkopony/plinkopony.cpp:53-96): a LinearTetStrain body falls on
     z-axis cylinders, a sphere and a floor; one CollisionForce over all nodes, weight 32."""
@@ -291,9 +324,16 @@ def make_collision():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "skin":
+        make_skin()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "projects":      # e.g.  make_golden.py projects TRI_AREA TRI_FUNG
+        make_projects(sys.argv[2:])
+        sys.exit(0)
     make_collision()
     make_projects()
     make_known_answers()
     make_bars()
     make_meshes()
     make_cloth()
+    make_skin()

@@ -20,4 +20,7 @@ int hm_project_hyper(int type, int M, const double *F, double mu, double lambda,
 void hm_project_tet_p(int volume, const double *d, double lmin, double lmax, double *p) {
     Mat3 r = volume ? project_tet_p<true>(ld(d), lmin, lmax) : project_tet_p<false>(ld(d), lmin, lmax); st(r, p);
 }
+void hm_svd32(const double *F, double *U2, double *S, double *V) { svd32(F, U2, S[0], S[1], V); }
+void hm_project_triarea_p(const double *d, int iters, double lmin, double lmax, double *p) { project_triarea_p(d, iters, lmin, lmax, p); }
+int hm_project_fung(const double *d, double mu, double *hess, double *z) { int it = 0; project_fung(d, mu, *hess, it, z); return it; }
 }

@@ -77,7 +77,7 @@ def oracle_local_step(o, xcur, n, rows):
 
 
 EXACT_CASES = [("TET_STVK", [100.0, 100.0, 5]), ("TET_STVK", [3e3, 1e3, 9]), ("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]),
-               ("BEND", [20.0]), ("SPRING", [50.0]), ("ANCHOR", [-1.0, 1.0])]
+               ("BEND", [20.0]), ("SPRING", [50.0]), ("ANCHOR", [-1.0, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_AREA", [30.0, 1, 1.0, 1.0])]
 
 
 @pytest.mark.parametrize("name,params", EXACT_CASES)
@@ -139,7 +139,30 @@ def test_local_step_triangle(pkg):
         s.write_local(0, u=u)
 
 
-@pytest.mark.parametrize("name", ["TET_STVK", "TET_LINEAR", "TET_VOLUME", "BEND", "SPRING", "ANCHOR", "TET_NH", "TRI_STRAIN"])
+def test_local_step_fung(pkg):
+    """FungTriangle: bit-exact 3x2 Jacobi SVD, then an L-BFGS whose objective calls exp() (OCML vs glibc):
+    like Neo-Hookean, nearly all elements agree to rounding, a few take a different line-search branch."""
+    n = 1200
+    s, o, X, idx, rng = build_disjoint(pkg, "TRI_FUNG", [50.0, 0.5, 2.0], n, seed=8)
+    differ = 0; total = 0
+    for it in range(4):
+        xcur = (X + [0.0, 0.02, 0.1, 0.3][it] * rng.normal(size=X.shape)).ravel()
+        s.local_step_only(xcur)
+        g = s.read_local(0)
+        u, z = oracle_local_step(o, xcur, n, 6)
+        fin = np.isfinite(z).all(axis=1) & np.isfinite(u).all(axis=1)
+        sc = np.maximum(1.0, np.abs(z[fin]).max(axis=1))
+        err = np.abs(g["z"][fin] - z[fin]).max(axis=1) / sc
+        differ += int((~(err < 1e-9)).sum()) + int((~fin).sum()); total += n
+        assert np.isfinite(g["z"][fin]).all() and err.max() < 0.1
+        st = np.array([o.hyper_state(i)[0] for i in range(n)])
+        u[~fin] = 0.0; st[~np.isfinite(st)] = 1.0
+        s.write_local(0, u=u, state=st)
+        ou = o._view("u", o.rows); ou[:] = u.ravel()            # the oracle continues from the same (sanitised) u
+    assert differ <= 0.03 * total, (differ, total)
+
+
+@pytest.mark.parametrize("name", ["TET_STVK", "TET_LINEAR", "TET_VOLUME", "BEND", "SPRING", "ANCHOR", "TET_NH", "TRI_STRAIN", "TRI_AREA", "TRI_FUNG"])
 def test_golden_project_tuples(pkg, name):
     """The committed per-project vectors captured from the COMPILED REFERENCE
     (tests/golden/project_*.npz), replayed through the GPU kernels: every fixture
@@ -160,7 +183,7 @@ def test_golden_project_tuples(pkg, name):
     if name.startswith("TET"):
         assert np.array_equal(rest["rest"], g["init"][:, 1:13])       # B, bit-exact
     s.write_local(0, u=g["u0"])
-    exact = name not in ("TET_NH", "TRI_STRAIN")
+    exact = name not in ("TET_NH", "TRI_STRAIN", "TRI_FUNG")
     bad = 0
     for c in range(g["Dx"].shape[1]):
         s.local_step_dx(0, g["Dx"][:, c])
@@ -171,9 +194,10 @@ def test_golden_project_tuples(pkg, name):
             if name == "TET_STVK":
                 assert np.array_equal(out["n_iters"], g["n_iters"][:, c])
         else:
-            sc = np.maximum(1.0, np.abs(g["z"][:, c]).max(axis=1))
-            err = np.abs(out["z"] - g["z"][:, c]).max(axis=1) / sc
-            if name == "TET_NH":
+            fin = np.isfinite(g["z"][:, c]).all(axis=1) & np.isfinite(g["u"][:, c]).all(axis=1)   # a few Fung tuples overflow in the reference
+            sc = np.maximum(1.0, np.abs(np.where(fin[:, None], g["z"][:, c], 0.0)).max(axis=1))
+            err = np.where(fin, np.abs(out["z"] - g["z"][:, c]).max(axis=1) / sc, 0.0)
+            if name in ("TET_NH", "TRI_FUNG"):
                 ok = err < 1e-9
                 bad += int((~ok).sum())
                 assert err.max() < 0.1
@@ -292,6 +316,27 @@ def test_cloth_fixture(pkg):
     for f in range(g["x_frames"].shape[0]):
         s.step(int(g["iters"]))
         assert np.abs(s.m_x - g["x_frames"][f]).max() < 1e-9   # continuous algorithm: tight
+
+
+@pytest.mark.parametrize("name", ["triarea", "fung"])
+def test_skin_fixtures(pkg, name):
+    """TriArea (+ bend) and FungTriangle membranes against the compiled reference's trajectories.
+    TriArea has no transcendental: tight.  Fung evaluates exp() inside a truncated L-BFGS, which the
+    reference itself amplifies (fixture ulp_sensitivity): 1e-9 or 1e4 x that envelope."""
+    g = golden("traj_skin_%s.npz" % name)
+    n = g["x"].shape[0]
+    s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
+    s.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
+    s.add_forces(int(g["kind"]), g["tris"], g["params"])
+    if bool(g["with_bend"]):
+        s.add_forces(KIND["BEND"], g["hinges"], [float(g["k_bend"])])
+    s.add_forces(KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
+    s.add_gravity([0, -9.8, 0])
+    s.initialize()
+    for f in range(g["x_frames"].shape[0]):
+        s.step(int(g["iters"]))
+        bound = 1e-9 if name == "triarea" else max(1e-9, 1e4 * float(g["ulp_sensitivity"][f]))
+        assert np.abs(s.m_x - g["x_frames"][f]).max() < bound, f
 
 
 def test_edge_cases(pkg):
@@ -436,25 +481,24 @@ def test_explicit_forces(pkg):
     for f in range(4):
         s.step(10); o.step()
         assert np.abs(s.m_x - o.x).max() < 1e-9
-    # wind: one frame from rest has v = dt*g on every node before the wind -> the serial and the
-    # two-pass evaluation differ only by the in-flight increments; compare against a numpy two-pass
+    # wind: the reference's loop in serial order (each triangle sees the increments of the ones before it)
     s = build(pkg.System(device_id=0)); s.set_timestep(0.04)
     w = s.add_explicit(pkg.EXPLICIT["WIND"], [10.0, 0.0, 2.0], tris)
     s.initialize()
     s.step(0)                                    # explicit forces only (admm_iters = 0): x += dt v
     v = s.m_v.reshape(-1, 3)
-    v0 = np.tile(0.04 * np.array([0, -9.8, 0]), (n, 1))
-    X = x
-    a = X[tris[:, 1]] - X[tris[:, 0]]; b = X[tris[:, 2]] - X[tris[:, 0]]
-    nrm = np.cross(a, b); nn = np.linalg.norm(nrm, axis=1, keepdims=True)
-    nh = nrm / nn; area = 0.5 * nn[:, 0]
-    vr = (v0[tris[:, 0]] + v0[tris[:, 1]] + v0[tris[:, 2]]) / 3.0 - np.array([10.0, 0, 2.0])
-    vn = (nh * vr).sum(1)
-    force = (-1000.0 * area * vn * np.abs(vn))[:, None] * nh * 0.33 * 0.04
-    vexp = v0.copy()
-    for c in range(3):
-        np.add.at(vexp, tris[:, c], force)
-    assert np.abs(v - vexp).max() < 1e-12 * max(1.0, np.abs(vexp).max())
+    vexp = np.tile(0.04 * np.array([0, -9.8, 0]), (n, 1))
+    wind = np.array([10.0, 0, 2.0])
+    for t in tris:
+        a = x[t[1]] - x[t[0]]; b = x[t[2]] - x[t[0]]
+        nrm = np.cross(a, b); nn = np.sqrt(nrm[0] * nrm[0] + (nrm[1] * nrm[1] + nrm[2] * nrm[2]))
+        nh = nrm / nn
+        vr = (vexp[t[0]] + vexp[t[1]] + vexp[t[2]]) / 3.0 - wind
+        vn = nh[0] * vr[0] + (nh[1] * vr[1] + nh[2] * vr[2])
+        force = (-1000.0 * (0.5 * nn) * vn * abs(vn)) * nh * 0.33 * 0.04
+        for c in range(3):
+            vexp[t[c]] += force
+    assert np.abs(v - vexp).max() < 1e-13 * max(1.0, np.abs(vexp).max())
     s.set_gravity(w, [0.0, 0.0, 0.0])            # direction is host-mutable (windyflag.cpp:141-152)
     s.step(5)
     assert np.isfinite(s.m_x).all()

@@ -21,6 +21,8 @@ def hm():
     lib = C.CDLL(out)
     lib.hm_project_hyper.argtypes = [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_int, dp, dp]
     lib.hm_project_tet_p.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
+    lib.hm_project_triarea_p.argtypes = [dp, C.c_int, C.c_double, C.c_double, dp]
+    lib.hm_project_fung.argtypes = [dp, C.c_double, dp, dp]
     return lib
 
 
@@ -80,3 +82,47 @@ def test_project_tet_blend(hm):
             b = Oracle.project_single(3 if vol else 2, x_rest, [100, 0.9, 1.1] if vol else [100.], d.reshape(1, 9), np.zeros(9))
             w = b["init"][0]; k = 100 * b["init"][13]; w2 = w * w
             assert np.array_equal((k * p + w2 * d) / (w2 + k), b["z"][0])
+
+
+def test_svd32(hm):
+    rng = np.random.default_rng(11)
+    for t in range(5000):
+        F = rng.normal(size=6) * 10 ** rng.uniform(-3, 3)
+        if t % 4 == 0:
+            F = (np.eye(3)[:, :2] + 0.3 * rng.normal(size=(3, 2))).ravel(order="F")
+        if t % 13 == 0:
+            F[3:6] = F[0:3] * rng.choice([1.0, -2.0])      # rank one
+        if t % 17 == 0:
+            F[1:3] = 0.0                                    # zero Householder tail
+        if t % 501 == 0:
+            F[:] = 0
+        a = Oracle.svd32(F)
+        U2 = np.zeros(6); S = np.zeros(2); V = np.zeros(4)
+        hm.hm_svd32(_p(F), _p(U2), _p(S), _p(V))
+        assert np.array_equal(a[0][:6], U2) and np.array_equal(a[1], S) and np.array_equal(a[2], V), t
+
+
+def test_project_triarea_and_fung(hm):
+    rng = np.random.default_rng(12)
+    x_rest = np.array([[0, 0, 0], [1, 0, 0], [0.2, 0.9, 0.1], [0, 0, 1.]])
+    for t in range(1500):
+        amp = rng.choice([0.0, 1e-8, 0.01, 0.1, 0.3, 0.6])
+        d = (np.eye(3)[:, :2] + amp * rng.normal(size=(3, 2))).ravel(order="F")
+        # TriArea: projection p, then the oracle's blend
+        p = np.zeros(6)
+        hm.hm_project_triarea_p(_p(d), 4, 0.9, 1.1, _p(p))
+        b = Oracle.project_single(KIND["TRI_AREA"], x_rest, [100., 4, 0.9, 1.1], d.reshape(1, 6), np.zeros(6))
+        w = b["init"][0]; k = 100 * b["init"][7]; w2 = w * w
+        assert np.array_equal((k * p + w2 * d) / (w2 + k), b["z"][0]), t
+        # Fung: two consecutive calls carrying the solver's Hessian guess
+        hess = np.array([1.0]); z = np.zeros(6)
+        d2 = (np.eye(3)[:, :2] + amp * rng.normal(size=(3, 2))).ravel(order="F")
+        b = Oracle.project_single(KIND["TRI_FUNG"], x_rest, [50., 0.5, 2.0], np.array([d, d2]), np.zeros(6))
+        u = np.zeros(6)
+        for c, dx in enumerate((d, d2)):
+            dd = dx + u
+            it = hm.hm_project_fung(_p(dd), 50.0, _p(hess), _p(z))
+            assert it == b["n_iters"][c], t
+            assert np.array_equal(z, b["z"][c], equal_nan=True), t
+            u = u + (dx - z)
+        assert hess[0] == b["state"][3] or (np.isnan(hess[0]) and np.isnan(b["state"][3]))

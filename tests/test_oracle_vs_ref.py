@@ -29,7 +29,7 @@ def test_svd_bit_exact():
 
 CASES = [("TET_NH", [1e5, 1e5, 5]), ("TET_NH", [50, 80, 20]), ("TET_STVK", [100, 100, 5]), ("TET_STVK", [3e3, 1e3, 12]), ("TET_LINEAR", [1.0]),
          ("TET_VOLUME", [100, 0.9, 1.1]), ("TRI_STRAIN", [100, .95, 1.05, 1]), ("TRI_STRAIN", [10, .5, 2, 0]), ("BEND", [20.]), ("SPRING", [50.]),
-         ("ANCHOR", [55., 1])]
+         ("ANCHOR", [55., 1]), ("TRI_AREA", [100., 4, .9, 1.1]), ("TRI_AREA", [7., 1, 1.0, 1.0]), ("TRI_FUNG", [50., 0.5, 2.0]), ("TRI_FUNG", [2e3, 0, 0])]
 
 
 @pytest.mark.parametrize("name,params", CASES)
@@ -57,8 +57,11 @@ def test_project_bit_exact(name, params):
         u0 = rng.normal(size=rows) * rng.choice([0, 0.01, 0.1])
         a = Ref.project_single(kind, x, params, np.array(Dx), u0)
         b = Oracle.project_single(kind, x, params, np.array(Dx), u0)
-        keys = ("z", "u", "init") + (("state", "n_iters") if name in ("TET_NH", "TET_STVK") else ())
+        keys = ("z", "u", "init") + (("state", "n_iters") if name in ("TET_NH", "TET_STVK", "TRI_FUNG") else ())
         for k in keys:
+            if k == "state" and name == "TRI_FUNG":   # only the solver's Hessian guess persists
+                assert a[k][3] == b[k][3], (name, t, k)
+                continue
             assert np.array_equal(a[k], b[k], equal_nan=True), (name, t, k)
 
 
