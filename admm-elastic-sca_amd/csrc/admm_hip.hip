@@ -255,17 +255,19 @@ int upload_factor(admm_hip_ctx *ctx) {
     if (!F.cg2.empty()) TRY(upload(ctx, &ctx->d_cg2, F.cg2));
     TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
     ctx->levels.assign(F.levels.size(), LevelDev());
+    // Split level: the first level holding a supernode wider than FWD_SMALL_KMAX.  Below it every forward item is
+    // a wave item and the backward kernel takes 4 columns per wave; from it upwards block items / ADMM_BWD_BIG_CW.
+    int split = (int)F.levels.size();
+    for (int l = 0; l < (int)F.levels.size() && split == (int)F.levels.size(); ++l) for (int s : F.levels[l]) if (F.sn[s].ncols > admm_dev::FWD_SMALL_KMAX) { split = l; break; }
     for (size_t l = 0; l < F.levels.size(); ++l) {
         LevelDev &L = ctx->levels[l];
         std::vector<int> ssn, stile, bsn, btile, wsn, wchunk;
-        int maxk = 0;
-        for (int s : F.levels[l]) maxk = std::max(maxk, F.sn[s].ncols);
-        L.bwd_cw = (maxk <= 64) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
+        L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
         for (int s : F.levels[l]) {
             const Supernode &S = F.sn[s];
             const int f = S.ncols + S.nrows;
             const int tiles = (f + 63) / 64;
-            for (int t = 0; t < tiles; ++t) { if (S.ncols <= admm_dev::FWD_SMALL_KMAX) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
+            for (int t = 0; t < tiles; ++t) { if ((int)l < split) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
             const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
             for (int c = 0; c < chunks; ++c) { wsn.push_back(s); wchunk.push_back(c); }
         }
@@ -465,21 +467,21 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     for (int l = 0; l < nl; ++l) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_small) {
-            if (F.cg2) hipLaunchKernelGGL(solve_fwd_small_kernel<true>, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL(solve_fwd_small_kernel<false>, dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
         }
         if (L.n_big) {
-            if (F.cg2) hipLaunchKernelGGL(solve_fwd_big_kernel<true>, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL(solve_fwd_big_kernel<false>, dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
         }
     }
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
     for (int l = nl - 1; l >= 0; --l) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_bwd) {
-            if (L.bwd_cw == 4) hipLaunchKernelGGL(solve_bwd_kernel<4>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 2) hipLaunchKernelGGL(solve_bwd_kernel<2>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
-            else hipLaunchKernelGGL(solve_bwd_kernel<1>, dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
         }
     }
     HIPCHK(hipGetLastError());
