@@ -84,6 +84,9 @@ def lib():
         L.admm_hip_destroy.argtypes = [C.c_void_p]
         L.admm_hip_destroy.restype = None
         L.admm_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.admm_hip_enable_residuals.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_set_tolerance.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.admm_hip_get_residuals.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         L.admm_hip_set_timestep.argtypes = [C.c_void_p, C.c_double]
         L.admm_hip_add_nodes.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int)]
         L.admm_hip_add_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _dp, C.POINTER(C.c_int)]
@@ -201,6 +204,19 @@ class System:
 
     def set_shard(self, rank, world):
         self._chk(self.L.admm_hip_set_shard(self.h, rank, world))
+
+    # ---- residuals / early exit (extension described at System.cpp:64-65) ----
+    def enable_residuals(self, on=True):
+        self._chk(self.L.admm_hip_enable_residuals(self.h, 1 if on else 0))
+
+    def set_tolerance(self, eps_r, eps_s, check_every=1):
+        self._chk(self.L.admm_hip_set_tolerance(self.h, float(eps_r), float(eps_s), int(check_every)))
+
+    def residuals(self, capacity=256):
+        r = np.zeros(capacity); s = np.zeros(capacity); n = C.c_int(0)
+        self._chk(self.L.admm_hip_get_residuals(self.h, _d(r), _d(s), capacity, C.byref(n)))
+        k = min(n.value, capacity)
+        return r[:k], s[:k], n.value
 
     def set_allreduce(self, pyfunc):
         """pyfunc(dev_ptr:int, count:int, stream:int) -> 0 on success."""

@@ -46,6 +46,8 @@ struct Batch {
     double *d_rest = nullptr, *d_par = nullptr, *d_w2h2 = nullptr, *d_kblend = nullptr, *d_w2 = nullptr;
     double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
+    double *d_u_prev = nullptr, *d_z_prev = nullptr, *d_G = nullptr;   // residual tracking only
+    std::vector<double> G;                // [12][n_local] selector block per element, corners in device order
 };
 
 struct Explicit {
@@ -95,6 +97,11 @@ struct admm_hip_ctx {
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
+    // residual tracking / early exit (off by default)
+    bool res_on = false, res_ready = false;
+    double tol_r = 0.0, tol_s = 0.0; int check_every = 1;
+    double *d_res = nullptr; int res_cap = 0, res_n = 0;      // [2 * res_cap]: r^2, s^2 per iteration
+    double *d_res_slots = nullptr, *d_res_s = nullptr, *d_res_partial = nullptr; int res_partial_n = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
@@ -285,6 +292,7 @@ int upload_all(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;
     HIPCHK(hipSetDevice(ctx->device_id));
     free_device(ctx);
+    ctx->res_ready = false;
     {
         std::vector<double> px = permute_nodes(ctx->x, F.perm, 3), pv = permute_nodes(ctx->v, F.perm, 3), pm = permute_nodes(ctx->m3, F.perm, 3);
         TRY(upload(ctx, &ctx->d_x, px)); TRY(upload(ctx, &ctx->d_v, pv)); TRY(upload(ctx, &ctx->d_m3, pm));
@@ -324,6 +332,7 @@ int upload_all(admm_hip_ctx *ctx) {
         const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
         const int nl = b.n_local;
         std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0), dst((size_t)std::max(nl, 1) * ist, 0);
+        b.G.assign((size_t)12 * std::max(nl, 1), 0.0);
         std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
         for (int el = 0; el < nl; ++el) {
             const int e = b.first + el;
@@ -341,6 +350,11 @@ int upload_all(admm_hip_ctx *ctx) {
                 for (int c = 0; c < 3; ++c) for (int r = 0; r < 2; ++r) rest[(size_t)(c + 3 * r) * nl + el] = R[ord[c] + 3 * r];
             } else {
                 for (int i = 0; i < 12; ++i) rest[(size_t)i * nl + el] = R[i];
+            }
+            {   // selector block in device corner order (residual tracking)
+                double Gm[4][3]; int cols;
+                element_G(b.kind, R, Gm, cols);
+                for (int c = 0; c < nn; ++c) for (int r = 0; r < 3; ++r) b.G[(size_t)(3 * c + r) * nl + el] = Gm[ord[c]][r];
             }
             for (int p = 0; p < np; ++p) par[(size_t)p * nl + el] = b.params[(size_t)e * np + p];
             const double w = b.weight[e];
@@ -484,6 +498,71 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
             else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
         }
     }
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
+// ---- residual tracking (opt-in): buffers are created on first use -------------------------------------
+int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
+    if (ctx->res_ready && iters <= ctx->res_cap) return ADMM_OK;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    if (!ctx->res_ready) {
+        int64_t slots = 0; int maxn = 0;
+        for (Batch &b : ctx->batches) {
+            const int rows = ADMM_KIND_ROWS[b.kind], nl = std::max(b.n_local, 1);
+            TRY(dalloc(ctx, &b.d_u_prev, (size_t)rows * nl)); TRY(dalloc(ctx, &b.d_z_prev, (size_t)rows * nl));
+            TRY(upload(ctx, &b.d_G, b.G));
+            slots += (int64_t)b.n_local * ADMM_KIND_NODES[b.kind]; maxn = std::max(maxn, b.n_local);
+        }
+        TRY(dalloc(ctx, &ctx->d_res_slots, 3 * (size_t)std::max<int64_t>(slots, 1)));
+        HIPCHK(hipMemset(ctx->d_res_slots, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slots, 1)));
+        TRY(dalloc(ctx, &ctx->d_res_s, 3 * (size_t)ctx->n_nodes));
+        ctx->res_partial_n = std::max((maxn + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK, (3 * ctx->n_nodes + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK);
+        TRY(dalloc(ctx, &ctx->d_res_partial, (size_t)std::max(ctx->res_partial_n, 1)));
+        ctx->res_ready = true; ctx->res_cap = 0;
+    }
+    if (iters > ctx->res_cap) { ctx->res_cap = std::max(iters, 64); TRY(dalloc(ctx, &ctx->d_res, 2 * (size_t)ctx->res_cap)); }
+    return ADMM_OK;
+}
+// before the local step: keep u and z of the previous iteration
+int residual_snapshot(admm_hip_ctx *ctx, bool first_iteration) {
+    for (Batch &b : ctx->batches) {
+        if (!b.n_local) continue;
+        const int rows = ADMM_KIND_ROWS[b.kind];
+        const size_t bytes = sizeof(double) * (size_t)rows * b.n_local;
+        HIPCHK(hipMemcpyAsync(b.d_u_prev, b.d_u, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (first_iteration)   // the reference warm-starts curr_z = D * m_x before the loop (System.cpp:43)
+            hipLaunchKernelGGL(admm_dev::residual_dx_kernel, dim3((b.n_local + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK), dim3(admm_dev::RES_BLOCK), 0, ctx->stream,
+                               b.n_local, ADMM_KIND_NODES[b.kind], rows / 3, idx_stride(b.kind), b.d_idx, b.d_G, ctx->d_x, b.d_z_prev);
+        else HIPCHK(hipMemcpyAsync(b.d_z_prev, b.d_z, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return ADMM_OK;
+}
+// after the local step: d_res[2 it] = |r|^2 (this rank's elements), d_res[2 it + 1] = |s|^2
+int launch_residuals(admm_hip_ctx *ctx, int it) {
+    using namespace admm_dev;
+    const int n3 = 3 * ctx->n_nodes;
+    double *r2 = ctx->d_res + 2 * (size_t)it, *s2 = r2 + 1;
+    bool first = true;
+    for (Batch &b : ctx->batches) {
+        if (!b.n_local) continue;
+        const int nb = (b.n_local + RES_BLOCK - 1) / RES_BLOCK, rows = ADMM_KIND_ROWS[b.kind];
+        hipLaunchKernelGGL(residual_primal_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, b.n_local, rows, b.d_u, b.d_u_prev, b.d_w2, ctx->d_res_partial);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, r2, first ? 0 : 1);
+        hipLaunchKernelGGL(residual_dual_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, b.n_local, ADMM_KIND_NODES[b.kind], rows / 3, idx_stride(b.kind),
+                           b.d_z, b.d_z_prev, b.d_w2, b.d_G, b.d_dst, ctx->d_res_slots);
+        first = false;
+    }
+    if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_res_slots, ctx->d_mxbar, 0, ctx->d_res_s);
+    if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
+        if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
+        if (ctx->allreduce(ctx->allreduce_user, ctx->d_res_s, (int64_t)n3, (void *)ctx->stream) != 0 || ctx->allreduce(ctx->allreduce_user, r2, 1, (void *)ctx->stream) != 0)
+            return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+    }
+    const int nb = (n3 + RES_BLOCK - 1) / RES_BLOCK;
+    hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, n3, ctx->d_res_s, ctx->d_res_partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, s2, 0);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -737,9 +816,15 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         hipLaunchKernelGGL(xbar_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
     }
     TRY(mark(ctx));
+    const bool track = ctx->res_on || ctx->tol_r > 0.0;
+    if (track) TRY(ensure_residual_buffers(ctx, admm_iters));
+    ctx->res_n = 0;
+    int iters_done = 0;
     for (int it = 0; it < admm_iters; ++it) {
+        if (track) TRY(residual_snapshot(ctx, it == 0));
         TRY(launch_local(ctx));
         TRY(mark(ctx));
+        if (track) { TRY(launch_residuals(ctx, it)); ctx->res_n = it + 1; }
         TRY(launch_rhs(ctx));
         TRY(mark(ctx));
         if (ctx->world > 1) {
@@ -754,7 +839,15 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         }
         TRY(launch_solve(ctx, mid));
         TRY(mark(ctx));
+        iters_done = it + 1;
+        if (ctx->tol_r > 0.0 && (it + 1) % ctx->check_every == 0 && it + 1 < admm_iters) {   // convergence test: one round trip
+            double rs[2];
+            HIPCHK(hipMemcpyAsync(rs, ctx->d_res + 2 * (size_t)it, sizeof rs, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (std::sqrt(rs[0]) <= ctx->tol_r && std::sqrt(rs[1]) <= ctx->tol_s) break;
+        }
     }
+    ctx->ev_iters = iters_done;
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
     HIPCHK(hipGetLastError());
     TRY(mark(ctx));
@@ -924,6 +1017,30 @@ int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info) {
     return ADMM_OK;
 }
 
+int admm_hip_enable_residuals(admm_hip_ctx *ctx, int on) {
+    if (!ctx) return ADMM_ERR_ARG;
+    ctx->res_on = on != 0;
+    return ADMM_OK;
+}
+int admm_hip_set_tolerance(admm_hip_ctx *ctx, double eps_r, double eps_s, int check_every) {
+    if (!ctx || check_every < 1 || eps_r < 0.0 || eps_s < 0.0) return ADMM_ERR_ARG;
+    ctx->tol_r = eps_r; ctx->tol_s = eps_s; ctx->check_every = check_every;
+    return ADMM_OK;
+}
+int admm_hip_get_residuals(admm_hip_ctx *ctx, double *r_norm, double *s_norm, int capacity, int *n_iters) {
+    TRY(require_device(ctx));
+    if (capacity < 0 || (capacity && (!r_norm || !s_norm))) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int n = std::min(ctx->res_n, capacity);
+    if (n > 0) {
+        std::vector<double> h(2 * (size_t)n);
+        HIPCHK(hipMemcpy(h.data(), ctx->d_res, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { r_norm[i] = std::sqrt(h[2 * (size_t)i]); s_norm[i] = std::sqrt(h[2 * (size_t)i + 1]); }
+    }
+    if (n_iters) *n_iters = ctx->ev_iters;
+    return ADMM_OK;
+}
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->timing = on != 0;

@@ -122,6 +122,78 @@ __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_p
 }
 
 // ---------------------------------------------------------------------------
+// Residuals (opt-in; the reference only describes them, System.cpp:64-65):
+//   r = W (Dx - z)            -- equals W (u_new - u_old), since every kind updates u += Dx - z
+//   s = D^T W^T W (z - z_prev)
+// Kind-agnostic: the element's selector block is the scalar matrix G (nodes x cols, the same one the
+// system matrix is assembled from), its rows are [cols][3].  All sums run in a fixed order.
+// ---------------------------------------------------------------------------
+constexpr int RES_BLOCK = 256;
+// partial[blockIdx] = sum over this block's elements of w2 * |u - u_prev|^2  (fixed tree inside the block)
+__global__ __launch_bounds__(RES_BLOCK) void residual_primal_kernel(int n, int rows, const double *__restrict__ u, const double *__restrict__ up,
+                                                                      const double *__restrict__ w2, double *__restrict__ partial) {
+    __shared__ double red[RES_BLOCK];
+    const int e = blockIdx.x * RES_BLOCK + threadIdx.x;
+    double a = 0.0;
+    if (e < n) {
+        for (int r = 0; r < rows; ++r) { const double d = u[(size_t)r * n + e] - up[(size_t)r * n + e]; a += d * d; }
+        a *= w2[e];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = RES_BLOCK / 2; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// per corner c: slot[dst[c]] = sum_r G[c][r] * w2 * (z - z_prev)[3r .. 3r+2]
+__global__ __launch_bounds__(RES_BLOCK) void residual_dual_kernel(int n, int nn, int cols, int ist, const double *__restrict__ z, const double *__restrict__ zp,
+                                                                    const double *__restrict__ w2, const double *__restrict__ G, const int *__restrict__ dst,
+                                                                    double *__restrict__ slots) {
+    const int e = blockIdx.x * RES_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const double w = w2[e];
+    double q[9];
+    for (int i = 0; i < 3 * cols; ++i) q[i] = w * (z[(size_t)i * n + e] - zp[(size_t)i * n + e]);
+    for (int c = 0; c < nn; ++c) {
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+        for (int r = 0; r < cols; ++r) { const double g = G[(size_t)(3 * c + r) * n + e]; o0 += g * q[3 * r]; o1 += g * q[3 * r + 1]; o2 += g * q[3 * r + 2]; }
+        double *o = slots + 3 * (size_t)dst[(size_t)ist * e + c];
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    }
+}
+// z_prev of a frame's first iteration is the reference's warm start curr_z = D * m_x (System.cpp:43)
+__global__ __launch_bounds__(RES_BLOCK) void residual_dx_kernel(int n, int nn, int cols, int ist, const int *__restrict__ idx, const double *__restrict__ G,
+                                                                  const double *__restrict__ x, double *__restrict__ out) {
+    const int e = blockIdx.x * RES_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    double acc[9];
+    for (int i = 0; i < 3 * cols; ++i) acc[i] = 0.0;
+    for (int c = 0; c < nn; ++c) {
+        const double *xn = x + 3 * (size_t)idx[(size_t)ist * e + c];
+        for (int r = 0; r < cols; ++r) { const double g = G[(size_t)(3 * c + r) * n + e]; acc[3 * r] += g * xn[0]; acc[3 * r + 1] += g * xn[1]; acc[3 * r + 2] += g * xn[2]; }
+    }
+    for (int i = 0; i < 3 * cols; ++i) out[(size_t)i * n + e] = acc[i];
+}
+__global__ __launch_bounds__(RES_BLOCK) void norm2_partial_kernel(int n, const double *__restrict__ v, double *__restrict__ partial) {
+    __shared__ double red[RES_BLOCK];
+    const int i = blockIdx.x * RES_BLOCK + threadIdx.x;
+    const double a = (i < n) ? v[i] * v[i] : 0.0;
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = RES_BLOCK / 2; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// out[0] (+)= sqrt-less sum of partial[0..n) in index order (one block, fixed strided order then tree)
+__global__ __launch_bounds__(RES_BLOCK) void sum_partials_kernel(int n, const double *__restrict__ partial, double *out, int accumulate) {
+    __shared__ double red[RES_BLOCK];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += RES_BLOCK) a += partial[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = RES_BLOCK / 2; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + red[0] : red[0];
+}
+
+// ---------------------------------------------------------------------------
 // triangular sweeps
 // ---------------------------------------------------------------------------
 struct FactorDev {
@@ -150,6 +222,18 @@ __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const 
     }
 }
 
+#ifndef ADMM_FWD_DEPTH
+#define ADMM_FWD_DEPTH 8          // panel columns per load group in the big forward kernel
+#endif
+#ifndef ADMM_FWD_SMALL_DEPTH
+#define ADMM_FWD_SMALL_DEPTH 8    // same for the narrow-supernode (wave per tile) forward kernel
+#endif
+#ifndef ADMM_BWD_UNROLL
+#define ADMM_BWD_UNROLL 4         // 64-row groups per load batch in the CW = 1 backward kernel
+#endif
+#ifndef ADMM_BWD_PREFETCH
+#define ADMM_BWD_PREFETCH 1       // CW > 1 backward kernel: first panel rows requested before the staging barrier
+#endif
 constexpr int FWD_SMALL_KMAX = 64;
 
 // Forward sweep, supernodes with k <= 64: one wave = one (supernode, 64-row tile);
@@ -174,9 +258,12 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     const int jend = row_ok ? ((i < k) ? i + 1 : k) : 0;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (row_ok && i >= k) child_sum<CG2>(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
-    double pre[4];
+    // first group of panel columns in flight before the staging barrier; afterwards the next group is
+    // always requested before the current one is consumed
+    constexpr int DS = ADMM_FWD_SMALL_DEPTH;
+    double cur[DS], nxt[DS];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] = (q < jend) ? P[(size_t)f * q] : 0.0;
+    for (int q = 0; q < DS; ++q) cur[q] = (q < jend) ? P[(size_t)f * q] : 0.0;
     if (live && lane < k) {
         const double *src = y + 3 * (size_t)(first + lane);
         double s0, s1, s2;
@@ -186,24 +273,14 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     __syncthreads();
     if (!row_ok) return;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    {
-        const double *t = &ts[wave][0];
+    for (int j = 0; j < jend; j += DS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (q < jend) { a0 += pre[q] * t[3 * q]; a1 += pre[q] * t[3 * q + 1]; a2 += pre[q] * t[3 * q + 2]; }
-    }
-    int j = 4;
-    for (; j + 4 <= jend; j += 4) {
-        const double p0 = P[(size_t)f * j], p1 = P[(size_t)f * (j + 1)], p2 = P[(size_t)f * (j + 2)], p3 = P[(size_t)f * (j + 3)];
+        for (int q = 0; q < DS; ++q) nxt[q] = (j + DS + q < jend) ? P[(size_t)f * (j + DS + q)] : 0.0;
         const double *t = &ts[wave][3 * j];
-        a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
-        a0 += p1 * t[3]; a1 += p1 * t[4]; a2 += p1 * t[5];
-        a0 += p2 * t[6]; a1 += p2 * t[7]; a2 += p2 * t[8];
-        a0 += p3 * t[9]; a1 += p3 * t[10]; a2 += p3 * t[11];
-    }
-    for (; j < jend; ++j) {
-        const double p0 = P[(size_t)f * j];
-        const double *t = &ts[wave][3 * j];
-        a0 += p0 * t[0]; a1 += p0 * t[1]; a2 += p0 * t[2];
+#pragma unroll
+        for (int q = 0; q < DS; ++q) if (j + q < jend) { a0 += cur[q] * t[3 * q]; a1 += cur[q] * t[3 * q + 1]; a2 += cur[q] * t[3 * q + 2]; }
+#pragma unroll
+        for (int q = 0; q < DS; ++q) cur[q] = nxt[q];
     }
     if (i < k) { double *dst = W + 3 * (size_t)(first + i); dst[0] = a0; dst[1] = a1; dst[2] = a2; }
     else {
@@ -216,12 +293,6 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
 // (supernode, 64-row tile); the 16 waves split the columns, partial sums are
 // combined through LDS in wave order.
 constexpr int FWD_BIG_KCHUNK = 2048;
-#ifndef ADMM_FWD_DEPTH
-#define ADMM_FWD_DEPTH 8          // panel columns per load group in the big forward kernel
-#endif
-#ifndef ADMM_BWD_UNROLL
-#define ADMM_BWD_UNROLL 4         // 64-row groups per load batch in the CW = 1 backward kernel
-#endif
 template <bool CG2>
 __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_tile,
                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
@@ -324,6 +395,12 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
     double acc[CW][3];
 #pragma unroll
     for (int c = 0; c < CW; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; }
+    // the panel does not depend on the staged vector: its first rows are requested before the staging barrier
+    double pf[CW];
+    if (CW != 1 && ADMM_BWD_PREFETCH) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { const int i = jc0 + lane; pf[c] = (j0 + c < k && i < f && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0; }
+    }
     // rows < jc0 are never needed by this block (lower triangular diagonal block)
     for (int r0 = jc0; r0 < f; r0 += BWD_RCHUNK) {
         const int rc = min(BWD_RCHUNK, f - r0);
@@ -356,8 +433,13 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
                     const int i = r0 + q;
                     const double *v = &vs[3 * q];
                     double p[CW];
+                    if (ADMM_BWD_PREFETCH && r0 == jc0 && q == lane) {
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) p[c] = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0;
+                        for (int c = 0; c < CW; ++c) p[c] = pf[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) p[c] = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0;
+                    }
 #pragma unroll
                     for (int c = 0; c < CW; ++c) { acc[c][0] += p[c] * v[0]; acc[c][1] += p[c] * v[1]; acc[c][2] += p[c] * v[2]; }
                 }
@@ -368,7 +450,11 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
     for (int c = 0; c < CW; ++c) {
         double a0 = acc[c][0], a1 = acc[c][1], a2 = acc[c][2];
 #pragma unroll
+#ifdef ADMM_BWD_FAKE_REDUCE   // timing experiment only (wrong results): one shuffle step instead of six
+        for (int off = 32; off >= 32; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
+#else
         for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
+#endif
         if (lane == 0 && j0 + c < k) {
             double *dst = X + 3 * (size_t)(first + j0 + c);
             dst[0] = a0; dst[1] = a1; dst[2] = a2;

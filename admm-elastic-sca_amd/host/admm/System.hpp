@@ -47,7 +47,12 @@ public:
         double timestep_s;
         int verbose;
         int admm_iters;
-        Settings() : timestep_s(0.04), verbose(1), admm_iters(10) {}
+        // extension (the reference only describes it, System.cpp:64-65): with residual_tol_primal > 0 a step's ADMM loop
+        // ends once |W(Dx-z)| <= residual_tol_primal and |D^T W^T W (z-z_prev)| <= residual_tol_dual, tested every
+        // residual_check_every iterations; admm_iters stays the upper bound.  0 (default) = the reference's fixed count.
+        double residual_tol_primal, residual_tol_dual;
+        int residual_check_every;
+        Settings() : timestep_s(0.04), verbose(1), admm_iters(10), residual_tol_primal(0.0), residual_tol_dual(0.0), residual_check_every(1) {}
     } settings;
 
     double elapsed_s;
@@ -159,6 +164,7 @@ public:
         for (size_t b = 0; b < batch_first.size(); ++b) if (batch_kind[b] == ADMM_KIND_COLLISION && !push_shapes(static_cast<CollisionForce *>(forces[batch_first[b]].get()))) return false;
         // m_x / m_v are public and may have been edited by the caller between steps
         if (!check(admm_hip_set_x(gpu, m_x.data())) || !check(admm_hip_set_v(gpu, m_v.data()))) return false;
+        if (!check(admm_hip_set_tolerance(gpu, settings.residual_tol_primal, settings.residual_tol_dual, settings.residual_check_every < 1 ? 1 : settings.residual_check_every))) return false;
         if (!check(admm_hip_step(gpu, settings.admm_iters))) return false;
         if (!check(admm_hip_get_x(gpu, m_x.data())) || !check(admm_hip_get_v(gpu, m_v.data()))) return false;
         // released MovingAnchors follow their node: point->pos = Dx (AnchorForce.cpp:80-83)

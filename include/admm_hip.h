@@ -185,6 +185,20 @@ typedef struct admm_hip_timing {
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on);
 int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t);
 
+/* ---- residuals and convergence-based early exit ------------------------------------------
+ * The reference only DESCRIBES these (comment at System.cpp:64-65, paper Eq. 22-23):
+ *     r = W (Dx - z)            primal residual, with the Dx the local step used
+ *     s = D^T W^T W (z - z_prev) dual residual
+ * With tracking on, every ADMM iteration of admm_hip_step also computes |r|_2 and |s|_2 (extra
+ * passes over u/z: about +20 % per iteration at 1M tets; off by default = the reference's loop).
+ * admm_hip_get_residuals copies the norms of the last step; *n_iters = ADMM iterations that step ran.
+ * admm_hip_set_tolerance(eps_r, eps_s, check_every): with eps_r > 0 the ADMM loop of a step ends as
+ * soon as |r| <= eps_r and |s| <= eps_s, tested every `check_every` iterations (each test is one
+ * host-device round trip); admm_iters stays the upper bound.  Tracking is switched on implicitly. */
+int admm_hip_enable_residuals(admm_hip_ctx *ctx, int on);
+int admm_hip_get_residuals(admm_hip_ctx *ctx, double *r_norm, double *s_norm, int capacity, int *n_iters);
+int admm_hip_set_tolerance(admm_hip_ctx *ctx, double eps_r, double eps_s, int check_every);
+
 #ifdef __cplusplus
 }
 #endif

@@ -985,6 +985,9 @@ struct orc_system {
     /* LDL^T of A (dof x dof) */
     int *Lp, *Li, *Parent; double *Lx, *Dg;
     int initialized;
+    /* residuals of the last step (the reference only describes them, CORE/System.cpp:64-65):
+     * r = W (Dx - z), s = D^T W^T W (z - z_prev); norms per ADMM iteration; tol > 0 ends the loop early */
+    double res_r[256], res_s[256]; int res_n; double tol_r, tol_s; int track_res;
 };
 
 orc_system *orc_create(void) {
@@ -1264,7 +1267,11 @@ int orc_step(orc_system *s) {
     spmv_D(s, s->x, s->z);                                  /* curr_z = D*m_x          :43 */
     double *M_xbar = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; ++i) { double xb = s->x[i] + dt * s->v[i]; M_xbar[i] = s->m[i] * xb; s->xc[i] = xb; } /* :46-48 */
+    double *zprev = NULL, *sv = NULL;
+    if (s->track_res) { zprev = (double *)malloc(sizeof(double) * R); sv = (double *)malloc(sizeof(double) * n); }
+    s->res_n = 0;
     for (int it = 0; it < s->admm_iters; ++it) {
+        if (s->track_res) memcpy(zprev, s->z, sizeof(double) * R);
         spmv_D(s, s->xc, s->Dx);                            /* Dx = D*curr_x           :54 */
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < s->n_forces; ++i) {             /* local step              :57-58 */
@@ -1280,12 +1287,32 @@ int orc_step(orc_system *s) {
         for (int i = 0; i < n; ++i) s->b[i] = M_xbar[i] + s->b[i];
         ldl_solve(s, s->b);                                 /* curr_x = solver.solve   :62 */
         for (int i = 0; i < n; ++i) s->xc[i] = s->b[i];
+        if (s->track_res) {                                 /* :64-65 (comment in the reference) */
+            double rr = 0.0, ss = 0.0;
+            for (int i = 0; i < n; ++i) sv[i] = 0.0;
+            for (int r = 0; r < R; ++r) {
+                double w = s->W[r], pr = w * (s->Dx[r] - s->z[r]);
+                rr += pr * pr;
+                double q = w * w * (s->z[r] - zprev[r]);
+                for (int p = s->Dp[r]; p < s->Dp[r + 1]; ++p) sv[s->Dj[p]] += s->Dv[p] * q;
+            }
+            for (int i = 0; i < n; ++i) ss += sv[i] * sv[i];
+            if (s->res_n < 256) { s->res_r[s->res_n] = sqrt(rr); s->res_s[s->res_n] = sqrt(ss); s->res_n++; }
+            if (s->tol_r > 0.0 && sqrt(rr) <= s->tol_r && sqrt(ss) <= s->tol_s) break;
+        }
     }
+    free(zprev); free(sv);
     for (int i = 0; i < n; ++i) { s->v[i] = (s->xc[i] - s->x[i]) * (1.0 / dt); s->x[i] = s->xc[i]; } /* :70-71 */
     free(M_xbar);
     return 1;
 }
 
+void orc_track_residuals(orc_system *s, int on, double tol_r, double tol_s) { s->track_res = on; s->tol_r = tol_r; s->tol_s = tol_s; }
+int orc_get_residuals(orc_system *s, double *r, double *sd, int cap) {
+    int n = s->res_n < cap ? s->res_n : cap;
+    for (int i = 0; i < n; ++i) { r[i] = s->res_r[i]; sd[i] = s->res_s[i]; }
+    return s->res_n;
+}
 int orc_dof(orc_system *s) { return s->dof; }
 int orc_rows(orc_system *s) { return s->nW; }
 int orc_n_forces(orc_system *s) { return s->n_forces; }

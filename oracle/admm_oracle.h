@@ -79,6 +79,11 @@ void orc_set_explicit_dir(orc_system *s, int which, const double *dir);
 void orc_set_collision_shapes(orc_system *s, int n, const int *types, const double *params);
 int  orc_initialize(orc_system *s);
 int  orc_step(orc_system *s);
+/* Residual norms per ADMM iteration of the last orc_step, as the comment at CORE/System.cpp:64-65 defines them:
+ * r = W (Dx - z) with the Dx the local step used, s = D^T W^T W (z - z_prev).  tol_r > 0: the ADMM loop of a
+ * step ends as soon as |r| <= tol_r and |s| <= tol_s.  (An extension: the reference never computes them.) */
+void orc_track_residuals(orc_system *s, int on, double tol_r, double tol_s);
+int  orc_get_residuals(orc_system *s, double *r, double *sdual, int cap);
 int  orc_dof(orc_system *s);
 int  orc_rows(orc_system *s);
 int  orc_n_forces(orc_system *s);

@@ -296,6 +296,9 @@ class Oracle(_Sys):
             lib.orc_force_project.argtypes = [C.POINTER(OrcForce), C.c_double, dp, dp, dp]
             lib.orc_add_explicit.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, ip]
             lib.orc_set_collision_shapes.argtypes = [C.c_void_p, C.c_int, ip, dp]
+            lib.orc_track_residuals.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+            lib.orc_track_residuals.restype = None
+            lib.orc_get_residuals.argtypes = [C.c_void_p, dp, dp, C.c_int]
             for n in ("settings", "set_layout", "add_gravity", "destroy", "get_D", "set_control_point", "svd3", "svd32", "add_explicit", "set_collision_shapes",
                       "oriented_svd", "force_construct", "force_initialize", "force_project"):
                 getattr(lib, "orc_" + n).restype = None
@@ -315,6 +318,14 @@ class Oracle(_Sys):
 
     def settings(self, dt, iters):
         self.lib.orc_settings(self.h, dt, iters)
+
+    def track_residuals(self, on=True, tol_r=0.0, tol_s=0.0):
+        self.lib.orc_track_residuals(self.h, int(on), float(tol_r), float(tol_s))
+
+    def residuals(self):
+        r = np.zeros(256); s = np.zeros(256)
+        n = self.lib.orc_get_residuals(self.h, _d(r), _d(s), 256)
+        return r[:n], s[:n], n
 
     def _view(self, name, n):
         p = getattr(self.lib, "orc_" + name)(self.h)

@@ -192,3 +192,29 @@ def test_skin_trajectories(name):
     for f in range(g["x_frames"].shape[0]):
         o.step()
         assert np.abs(o.x - g["x_frames"][f]).max() < tol(g, f)
+
+
+def test_residuals_and_early_exit():
+    """r = W(Dx - z), s = D^T W^T W (z - z_prev) (the reference describes them at System.cpp:64-65, never computes
+    them): both fall over the iterations of a frame, and a tolerance ends the loop early."""
+    g = golden("traj_cloth.npz")
+    n = g["x"].shape[0]
+
+    def build():
+        o = Oracle(); o.settings(float(g["dt"]), 30)
+        o.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
+        o.add_forces(KIND["TRI_STRAIN"], g["tris"], [float(g["k_tri"]), g["lim"][0], g["lim"][1], 1.0])
+        o.add_forces(KIND["BEND"], g["hinges"], [float(g["k_bend"])])
+        o.add_forces(KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
+        o.add_gravity([0, -9.8, 0])
+        assert o.initialize()
+        return o
+    o = build(); o.track_residuals(True)
+    o.step()
+    r, s, it = o.residuals()
+    assert it == 30 and np.all(np.isfinite(r)) and np.all(np.isfinite(s))
+    assert r[-1] < 0.2 * r[0] and s[-1] < 0.2 * s.max()
+    assert np.abs(o.x - g["x_frames"][0]).max() < tol(g, 0)        # tracking does not change the step
+    o2 = build(); o2.track_residuals(True, tol_r=float(r[9]) * 1.0001, tol_s=float(s.max()) * 2)
+    o2.step()
+    assert o2.residuals()[2] == 10                                 # stops at the first iteration whose |r| reaches the tolerance
