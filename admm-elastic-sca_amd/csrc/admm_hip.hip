@@ -62,9 +62,9 @@ struct Explicit {
 #define ADMM_BWD_BIG_CW 1            // backward kernel: columns per wave on levels with supernodes wider than 64
 #endif
 struct LevelDev {
-    int n_small = 0; int *d_small_sn = nullptr, *d_small_tile = nullptr;
-    int n_big = 0; int *d_big_sn = nullptr, *d_big_tile = nullptr;
-    int n_bwd = 0, bwd_cw = 1; int *d_bwd_sn = nullptr, *d_bwd_chunk = nullptr;
+    int n_small = 0; admm_dev::SweepItem *d_small = nullptr;   // forward: wave items (levels below the split)
+    int n_big = 0; admm_dev::SweepItem *d_big = nullptr;       // forward: block items
+    int n_bwd = 0, bwd_cw = 1; admm_dev::SweepItem *d_bwd = nullptr;
 };
 
 } // namespace
@@ -268,20 +268,21 @@ int upload_factor(admm_hip_ctx *ctx) {
     for (int l = 0; l < (int)F.levels.size() && split == (int)F.levels.size(); ++l) for (int s : F.levels[l]) if (F.sn[s].ncols > admm_dev::FWD_SMALL_KMAX) { split = l; break; }
     for (size_t l = 0; l < F.levels.size(); ++l) {
         LevelDev &L = ctx->levels[l];
-        std::vector<int> ssn, stile, bsn, btile, wsn, wchunk;
+        std::vector<admm_dev::SweepItem> sm, bg, bw;
         L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
         for (int s : F.levels[l]) {
             const Supernode &S = F.sn[s];
+            admm_dev::SweepItem it{};
+            it.s = s; it.k = S.ncols; it.r = S.nrows; it.first = S.first;
+            it.panel_off = S.panel_off; it.front_off = S.front_off; it.slot_off = S.slot_off; it.rows_off = S.rows_off;
             const int f = S.ncols + S.nrows;
             const int tiles = (f + 63) / 64;
-            for (int t = 0; t < tiles; ++t) { if ((int)l < split) { ssn.push_back(s); stile.push_back(t); } else { bsn.push_back(s); btile.push_back(t); } }
+            for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
             const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
-            for (int c = 0; c < chunks; ++c) { wsn.push_back(s); wchunk.push_back(c); }
+            for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
         }
-        L.n_small = (int)ssn.size(); L.n_big = (int)bsn.size(); L.n_bwd = (int)wsn.size();
-        TRY(upload(ctx, &L.d_small_sn, ssn)); TRY(upload(ctx, &L.d_small_tile, stile));
-        TRY(upload(ctx, &L.d_big_sn, bsn)); TRY(upload(ctx, &L.d_big_tile, btile));
-        TRY(upload(ctx, &L.d_bwd_sn, wsn)); TRY(upload(ctx, &L.d_bwd_chunk, wchunk));
+        L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
+        TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
     }
     return ADMM_OK;
 }
@@ -481,21 +482,21 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     for (int l = 0; l < nl; ++l) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_small) {
-            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small_sn, L.d_small_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
         }
         if (L.n_big) {
-            if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big_sn, L.d_big_tile, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
         }
     }
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
     for (int l = nl - 1; l >= 0; --l) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_bwd) {
-            if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
-            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd_sn, L.d_bwd_chunk, F, ctx->d_w, ctx->d_xcur);
+            if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
         }
     }
     HIPCHK(hipGetLastError());

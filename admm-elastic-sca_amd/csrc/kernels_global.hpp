@@ -206,6 +206,17 @@ struct FactorDev {
     const int2 *cg2;         // same lists as fixed pairs (binary elimination trees), or NULL
 };
 
+// One work item of a sweep launch with everything the block needs to start, in one 64-byte record
+// (one scalar load instead of an index load followed by six dependent per-supernode loads).
+struct __attribute__((aligned(16))) SweepItem {
+    int s, part;                 // supernode; 64-row tile (forward) or column chunk (backward)
+    int k, r;                    // columns, below-diagonal rows
+    int first, pad;              // first column in factor order
+    long long panel_off, front_off, slot_off, rows_off;
+    long long pad2;
+};
+static_assert(sizeof(SweepItem) == 64, "SweepItem is one 64-byte record");
+
 // sum of the children's contributions that land on front row `fr` (fixed child order)
 template <bool CG2>
 __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const double *__restrict__ C, double &s0, double &s1, double &s2) {
@@ -242,19 +253,19 @@ constexpr int FWD_SMALL_KMAX = 64;
 // row, the first panel columns) is requested before the staging barrier so that the
 // dependent index -> slot -> value chain overlaps with the panel stream.
 template <bool CG2>
-__global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const int *__restrict__ item_sn, const int *__restrict__ item_tile,
+__global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const SweepItem *__restrict__ items,
                                                               FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
     __shared__ double ts[4][FWD_SMALL_KMAX * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + wave;
     const bool live = item < n_items;
-    int s = 0, tile = 0, k = 0, r = 0, first = 0;
-    int64_t foff = 0;
-    if (live) { s = item_sn[item]; tile = item_tile[item]; k = F.sn_ncols[s]; r = F.sn_nrows[s]; first = F.sn_first[s]; foff = F.sn_front_off[s]; }
+    int tile = 0, k = 0, r = 0, first = 0;
+    int64_t foff = 0, poff = 0, soff = 0;
+    if (live) { const SweepItem it = items[item]; tile = it.part; k = it.k; r = it.r; first = it.first; foff = it.front_off; poff = it.panel_off; soff = it.slot_off; }
     const int f = k + r;
     const int i = tile * 64 + lane;
     const bool row_ok = live && i < f;
-    const double *P = F.panels + (live ? F.sn_panel_off[s] : 0) + (row_ok ? i : 0);
+    const double *P = F.panels + poff + (row_ok ? i : 0);
     const int jend = row_ok ? ((i < k) ? i + 1 : k) : 0;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (row_ok && i >= k) child_sum<CG2>(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
     }
     if (i < k) { double *dst = W + 3 * (size_t)(first + i); dst[0] = a0; dst[1] = a1; dst[2] = a2; }
     else {
-        double *dst = C + 3 * (size_t)(F.sn_slot_off[s] + (i - k));
+        double *dst = C + 3 * (size_t)(soff + (i - k));
         dst[0] = a0 + c0; dst[1] = a1 + c1; dst[2] = a2 + c2;
     }
 }
@@ -294,18 +305,18 @@ __global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const
 // combined through LDS in wave order.
 constexpr int FWD_BIG_KCHUNK = 2048;
 template <bool CG2>
-__global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_tile,
+__global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__restrict__ items,
                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
     __shared__ double ts[FWD_BIG_KCHUNK * 3];
     __shared__ double red[16][64 * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = item_sn[blockIdx.x], tile = item_tile[blockIdx.x];
-    const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
-    const int64_t foff = F.sn_front_off[s];
+    const SweepItem it = items[blockIdx.x];
+    const int tile = it.part, k = it.k, r = it.r, first = it.first;
+    const int64_t foff = it.front_off;
     const int f = k + r;
     const int i = tile * 64 + lane;
     const bool row_ok = i < f;
-    const double *P = F.panels + F.sn_panel_off[s] + (row_ok ? i : 0);
+    const double *P = F.panels + it.panel_off + (row_ok ? i : 0);
     const int jend = (i < k) ? i + 1 : k;
     // columns beyond the tile's last row never contribute to a tile inside the triangle
     const int kneed = min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
 #pragma unroll
             for (int w = 1; w < 16; ++w) acc += red[w][3 * ln + c];
             if (row < k) W[3 * (size_t)(first + row) + c] = acc;
-            else C[3 * (size_t)(F.sn_slot_off[s] + (row - k)) + c] = acc + carry;
+            else C[3 * (size_t)(it.slot_off + (row - k)) + c] = acc + carry;
         }
     }
 }
@@ -379,19 +390,40 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const int *__restri
 // workgroup barriers between levels -- fewer launches but 5-20 % slower, the
 // per-level launches expose more parallelism to hide the dependent index ->
 // slot -> value loads.)
+// Sum n per-lane values across the 64 lanes of a wave with a transposing butterfly: at every one of the six
+// steps a lane keeps one half of its values and receives its partner's copies of that half, so the count
+// halves while all lanes stay busy: 14 shuffles for 12 values (7 for 3) instead of 6 per value.  Fixed
+// pairwise order.  On return, lanes with cnt >= 1 hold in v[0] the wave total of value index `base`.
+template <int n, int off>
+__device__ __forceinline__ void wave_sum_transpose(double *v, int lane, int &base, int &cnt) {
+    constexpr int h = (n + 1) / 2;
+    const bool up = (lane & off) != 0;
+    double keep[h], recv[h];
+#pragma unroll
+    for (int t = 0; t < h; ++t) {
+        const double lo = v[t], hi = (h + t < n) ? v[h + t] : 0.0;
+        keep[t] = up ? hi : lo;
+        recv[t] = __shfl_xor(up ? lo : hi, off, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < h; ++t) v[t] = keep[t] + recv[t];
+    if (up) { base += h; cnt = max(cnt - h, 0); } else cnt = min(cnt, h);
+    if constexpr (off > 1) wave_sum_transpose<h, off / 2>(v, lane, base, cnt);
+}
+
 constexpr int BWD_RCHUNK = 1024;
 template <int CW>
-__global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ item_sn, const int *__restrict__ item_chunk,
+__global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restrict__ items,
                                                         FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
     __shared__ double vs[BWD_RCHUNK * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = item_sn[blockIdx.x], chunk = item_chunk[blockIdx.x];
-    const int k = F.sn_ncols[s], r = F.sn_nrows[s], first = F.sn_first[s];
+    const SweepItem it = items[blockIdx.x];
+    const int chunk = it.part, k = it.k, r = it.r, first = it.first;
     const int f = k + r;
-    const int *rows = F.rows + F.sn_rows_off[s];
+    const int *rows = F.rows + it.rows_off;
     const int jc0 = chunk * (4 * CW);           // first column of this block
     const int j0 = jc0 + wave * CW;             // this wave's first column
-    const double *Pj = F.panels + F.sn_panel_off[s] + (size_t)f * min(j0, k - 1);
+    const double *Pj = F.panels + it.panel_off + (size_t)f * min(j0, k - 1);
     double acc[CW][3];
 #pragma unroll
     for (int c = 0; c < CW; ++c) { acc[c][0] = 0.0; acc[c][1] = 0.0; acc[c][2] = 0.0; }
@@ -446,19 +478,14 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const int *__restrict__ 
             }
         }
     }
+    double v[3 * CW];
 #pragma unroll
-    for (int c = 0; c < CW; ++c) {
-        double a0 = acc[c][0], a1 = acc[c][1], a2 = acc[c][2];
-#pragma unroll
-#ifdef ADMM_BWD_FAKE_REDUCE   // timing experiment only (wrong results): one shuffle step instead of six
-        for (int off = 32; off >= 32; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
-#else
-        for (int off = 32; off >= 1; off >>= 1) { a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64); a2 += __shfl_down(a2, off, 64); }
-#endif
-        if (lane == 0 && j0 + c < k) {
-            double *dst = X + 3 * (size_t)(first + j0 + c);
-            dst[0] = a0; dst[1] = a1; dst[2] = a2;
-        }
+    for (int c = 0; c < CW; ++c) { v[3 * c] = acc[c][0]; v[3 * c + 1] = acc[c][1]; v[3 * c + 2] = acc[c][2]; }
+    int base = 0, cnt = 3 * CW;
+    wave_sum_transpose<3 * CW, 32>(v, lane, base, cnt);
+    if (cnt >= 1) {
+        const int c = base / 3, m = base - 3 * c;
+        if (j0 + c < k) X[3 * (size_t)(first + j0 + c) + m] = v[0];
     }
 }
 
