@@ -176,15 +176,24 @@ def main():
     ach = by / sec / 1e9 if sec > 0 else 0.0
     # HBM traffic of the dominant kernel from the PMC passes committed under profiles/
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; same workload, 1 GPU).
+    # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of coalesced streaming reads -- calibrated on
+    # this code's own 8-B-per-lane pattern: epilogue_kernel reads 2 x 4.29 MB and shows 4.30 MB, prologue_kernel 12.86 -> 6.44 MB;
+    # WRITE_SIZE is exact (8.57 / 12.86 MB).  So traffic = 2 x FETCH_SIZE + WRITE_SIZE.
     traffic = None
+    valu = None
     try:
         if (nx, ny, nz) == (32, 32, 163) and world == 1 and dom.startswith("project_tet_kernel"):
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_1M.json")))["kernels"]["admm_dev::project_tet_kernel<0, 5>"]
-            traffic = (pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
+            traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
+            # the kernel is fp64-VALU-issue bound, not HBM bound: share of a wave's life spent issuing VALU work, x 2 resident waves per SIMD
+            busy = pm["SQ_ACTIVE_INST_VALU"]["per_launch"] / pm["SQ_WAVE_CYCLES"]["per_launch"]
+            valu = {"valu_insts_per_launch": pm["SQ_INSTS_VALU"]["per_launch"], "fma_f64_insts": pm["SQ_INSTS_VALU_FMA_F64"]["per_launch"],
+                    "valu_busy_per_wave": busy, "waves_per_simd": 2, "simd_valu_issue_frac": min(1.0, 2 * busy),
+                    "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"])}
     except Exception:
         traffic = None
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3,
+            "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
             "phases_ms_per_iter": {k: v / iters_total for k, v in phase.items()},
             "all": {k: {"GB/s": (v[0] / v[1] / 1e9 if v[1] > 0 else 0.0), "ms": v[1] * 1e3} for k, v in cands.items()}}
 
