@@ -97,6 +97,10 @@ struct admm_hip_ctx {
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
+    // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
+    // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
+    // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
+    bool graph_enabled = true; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     // residual tracking / early exit (off by default)
     bool res_on = false, res_ready = false;
     double tol_r = 0.0, tol_s = 0.0; int check_every = 1;
@@ -138,6 +142,8 @@ template <class T> int upload(admm_hip_ctx *ctx, T **p, const std::vector<T> &h)
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 void free_device(admm_hip_ctx *ctx) {
+    if (ctx->iter_exec) { (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr; }
+    if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
     ctx->levels.clear();
@@ -601,6 +607,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     ctx->info.device_id = device_id; ctx->info.world = 1;
     const char *ls = getenv("ADMM_HIP_LEAF");
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
+    if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
     *out = ctx;
     return ADMM_OK;
 }
@@ -819,9 +826,24 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     TRY(mark(ctx));
     const bool track = ctx->res_on || ctx->tol_r > 0.0;
     if (track) TRY(ensure_residual_buffers(ctx, admm_iters));
+    const bool use_graph = ctx->graph_enabled && ctx->world == 1 && !ctx->timing && !track && admm_iters > 0;
+    if (use_graph && !ctx->iter_exec) {   // capture one iteration; every kernel argument is a fixed device address
+        HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        int rc = launch_local(ctx);
+        if (!rc) rc = launch_rhs(ctx);
+        if (!rc) rc = launch_solve(ctx, nullptr);
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+        if (rc || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); ctx->graph_enabled = false; fprintf(stderr, "admm_hip: graph capture unavailable, launching eagerly\n"); }
+        else {
+            ctx->iter_graph = g;
+            if (hipGraphInstantiate(&ctx->iter_exec, g, nullptr, nullptr, 0) != hipSuccess) { ctx->iter_exec = nullptr; (void)hipGraphDestroy(g); ctx->iter_graph = nullptr; (void)hipGetLastError(); ctx->graph_enabled = false; }
+        }
+    }
     ctx->res_n = 0;
     int iters_done = 0;
     for (int it = 0; it < admm_iters; ++it) {
+        if (use_graph && ctx->iter_exec) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
         if (track) TRY(residual_snapshot(ctx, it == 0));
         TRY(launch_local(ctx));
         TRY(mark(ctx));

@@ -212,7 +212,7 @@ def main():
         "roofline": roof,
     }
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 side figure
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_dims)
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it

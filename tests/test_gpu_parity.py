@@ -382,6 +382,34 @@ def test_residuals_and_early_exit(pkg):
     assert it == 12 and np.abs(r - ro).max() < 1e-4 * ro.max() and np.abs(sd - so).max() < 1e-4 * so.max()
 
 
+def test_graph_replay_matches_eager_launches(pkg, monkeypatch):
+    """admm_hip_step replays one captured ADMM iteration per iteration (HIP graph); same kernels, same arguments:
+    bitwise equal to launching them one by one -- over several frames, with a moving anchor retargeted between frames
+    (host-mutable parameters live in device buffers the captured kernels read) and after recompute_weights (graph rebuilt)."""
+    out = []
+    for g in ("0", "1"):
+        monkeypatch.setenv("ADMM_HIP_GRAPH", g)
+        mg = pkg.meshgen
+        x, t = mg.bar(3, 3, 10)
+        m = mg.lumped_tet_mass(x, t, 1000.0)
+        s = pkg.System(device_id=0); s.set_timestep(0.04)
+        s.add_nodes(x.ravel(), np.repeat(m, 3))
+        s.add_forces(KIND["TET_STVK"], t, [1e5, 1e5, 5])
+        s.add_forces(KIND["ANCHOR"], mg.bar_anchor_nodes(3, 3), [-1.0, 1.0])
+        tip = x.shape[0] - 1
+        b = s.add_forces(KIND["ANCHOR"], [tip], [-1.0, 1.0], targets=x[tip][None, :])   # targets given = MovingAnchor
+        s.add_gravity([0, -9.8, 0])
+        s.initialize()
+        for f in range(4):
+            s.update_anchors(b, targets=(x[tip] + [0.02 * f, 0.0, 0.0])[None, :], active=[1 if f < 3 else 0])
+            s.step(10)
+        w = s.read_rest(0)["weight"] * 1.5
+        s.set_weights(0, w); s.recompute_weights()
+        s.step(10)
+        out.append(s.m_x.copy())
+    assert np.array_equal(out[0], out[1])
+
+
 def test_edge_cases(pkg):
     # empty batches, a single element, moving anchors (active and released)
     s = pkg.System(device_id=0); s.set_timestep(0.04)
