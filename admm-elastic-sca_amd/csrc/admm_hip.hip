@@ -97,6 +97,8 @@ struct admm_hip_ctx {
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
+    // small systems: explicit inverse of the scalar system (factor order), one kernel per solve
+    int dense_max = 2048; bool dense = false; std::vector<double> Ainv; double *d_ainv = nullptr;
     // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
     // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
     // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
@@ -242,6 +244,25 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         }
     }
     ctx->info.t_order_s = F.t_order; ctx->info.t_symbolic_s = F.t_symbolic; ctx->info.t_numeric_s = F.t_numeric;
+    // small system: form A_s^-1 in factor order with the factor itself, three unit vectors per solve
+    const int n = F.n;
+    ctx->dense = n > 0 && n <= ctx->dense_max;
+    ctx->info.dense_solve = ctx->dense ? 1 : 0;
+    ctx->Ainv.clear();
+    if (ctx->dense) {
+        const double t0 = now_s();
+        ctx->Ainv.assign((size_t)n * n, 0.0);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+        for (int j0 = 0; j0 < n; j0 += 3) {
+            std::vector<double> b(3 * (size_t)n, 0.0), x(3 * (size_t)n);
+            for (int c = 0; c < 3 && j0 + c < n; ++c) b[3 * (size_t)F.perm[j0 + c] + c] = 1.0;
+            panel_solve_host(F, b.data(), x.data());
+            for (int c = 0; c < 3 && j0 + c < n; ++c) for (int i = 0; i < n; ++i) ctx->Ainv[(size_t)i * n + j0 + c] = x[3 * (size_t)F.perm[i] + c];
+        }
+        // symmetrise (the two triangles differ by rounding): rows are what the kernel streams
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) { const double a = 0.5 * (ctx->Ainv[(size_t)i * n + j] + ctx->Ainv[(size_t)j * n + i]); ctx->Ainv[(size_t)i * n + j] = a; ctx->Ainv[(size_t)j * n + i] = a; }
+        ctx->info.t_numeric_s += now_s() - t0;
+    }
     return ADMM_OK;
 }
 
@@ -267,6 +288,8 @@ int upload_factor(admm_hip_ctx *ctx) {
     ctx->d_cg2 = nullptr;
     if (!F.cg2.empty()) TRY(upload(ctx, &ctx->d_cg2, F.cg2));
     TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
+    ctx->d_ainv = nullptr;
+    if (ctx->dense) TRY(upload(ctx, &ctx->d_ainv, ctx->Ainv));
     ctx->levels.assign(F.levels.size(), LevelDev());
     // Split level: the first level holding a supernode wider than FWD_SMALL_KMAX.  Below it every forward item is
     // a wave item and the backward kernel takes 4 columns per wave; from it upwards block items / ADMM_BWD_BIG_CW.
@@ -483,6 +506,12 @@ int launch_rhs(admm_hip_ctx *ctx) {
 // both triangular sweeps: d_y (rhs, destroyed) -> d_xcur
 int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     using namespace admm_dev;
+    if (ctx->dense) {   // small system: one kernel, x = A_s^-1 b
+        if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
+        hipLaunchKernelGGL(dense_solve_kernel, dim3((ctx->n_nodes + 3) / 4), dim3(256), 0, ctx->stream, ctx->n_nodes, (const double *)ctx->d_ainv, (const double *)ctx->d_y, ctx->d_xcur);
+        HIPCHK(hipGetLastError());
+        return ADMM_OK;
+    }
     const FactorDev F = factor_dev(ctx);
     const int nl = (int)ctx->levels.size();
     for (int l = 0; l < nl; ++l) {
@@ -608,6 +637,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     const char *ls = getenv("ADMM_HIP_LEAF");
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
     if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_DENSE_MAX")) ctx->dense_max = atoi(g);
     *out = ctx;
     return ADMM_OK;
 }
@@ -769,6 +799,7 @@ int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
         HIPCHK(hipSetDevice(ctx->device_id));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (ctx->dense && ctx->d_ainv) HIPCHK(hipMemcpy(ctx->d_ainv, ctx->Ainv.data(), ctx->Ainv.size() * sizeof(double), hipMemcpyHostToDevice));
         for (Batch &b : ctx->batches) {
             const int nl = b.n_local;
             std::vector<double> w2h2(std::max(nl, 1)), w2(std::max(nl, 1));

@@ -489,4 +489,26 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restr
     }
 }
 
+// Small systems: x = A_s^-1 b with the explicit (symmetric) inverse, one wave per row, 4 rows per block; lanes stride
+// over the columns (coalesced 512-B reads of the row, 1.5 KB of b), fixed-order lane sums, transposing butterfly.
+__global__ __launch_bounds__(256) void dense_solve_kernel(int n, const double *__restrict__ Ainv, const double *__restrict__ b, double *__restrict__ X) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    const double *row = Ainv + (size_t)i * n;
+    double v[3] = {0.0, 0.0, 0.0};
+    int j = lane;
+    for (; j + 192 < n; j += 256) {
+        double a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = row[j + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double *bj = b + 3 * (size_t)(j + 64 * q); v[0] += a[q] * bj[0]; v[1] += a[q] * bj[1]; v[2] += a[q] * bj[2]; }
+    }
+    for (; j < n; j += 64) { const double a = row[j]; const double *bj = b + 3 * (size_t)j; v[0] += a * bj[0]; v[1] += a * bj[1]; v[2] += a * bj[2]; }
+    int base = 0, cnt = 3;
+    wave_sum_transpose<3, 32>(v, lane, base, cnt);
+    if (cnt >= 1) X[3 * (size_t)i + base] = v[0];
+}
+
 } // namespace admm_dev

@@ -107,6 +107,9 @@ int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *us
  * weights, global_idx), assembly of A = M + dt^2 D^T W^2 D, its sparse
  * factorization (host) and the upload of every device-resident array.        */
 int admm_hip_finalize(admm_hip_ctx *ctx);
+/* Small systems (n_nodes <= ADMM_HIP_DENSE_MAX, default 2048; env, 0 disables): the factor is used once on the host to
+ * form the dense A_s^-1 (n x n, <= 33 MB) and every solve becomes ONE kernel, x = A_s^-1 b, instead of ~2 launches per
+ * elimination-tree level whose dependent latencies dominate at this size (the reference's shipped scenes have 777-1251 nodes). */
 
 /* replaces: System::recompute_weights()                   (System.cpp:159-179)
  * after admm_hip_set_weights changed per-element weights: re-assemble, re-factor, re-upload. */
@@ -173,6 +176,8 @@ typedef struct admm_hip_info {
     int64_t solve_contrib_rows; /* sum of below-diagonal block rows            */
     double  t_order_s, t_symbolic_s, t_numeric_s, t_upload_s; /* finalize phases */
     int32_t rank, world, device_id, host_threads;
+    int32_t dense_solve;      /* 1: small system, solved as x = A_s^-1 b with the explicit inverse (see admm_hip_finalize) */
+    int32_t reserved;
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
 

@@ -225,9 +225,13 @@ def _bar_pair(pkg, kind, dims, iters):
     return s, o
 
 
-def test_solve_residual_and_vs_oracle(pkg):
+@pytest.mark.parametrize("dense_max", ["0", "2048"])
+def test_solve_residual_and_vs_oracle(pkg, monkeypatch, dense_max):
+    """both solve paths: the supernodal panel sweeps (dense_max 0) and, for small systems, x = A^-1 b with the explicit inverse"""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", dense_max)
     s, o = _bar_pair(pkg, KIND["TET_NH"], (6, 5, 17), 1)
     n = s.n_nodes
+    assert s.info()["dense_solve"] == (1 if dense_max != "0" else 0)
     rng = np.random.default_rng(0)
     for _ in range(3):
         b = rng.normal(size=3 * n)
@@ -380,6 +384,32 @@ def test_residuals_and_early_exit(pkg):
     r, sd, it = sb.residuals(); ro, so, _ = ob.residuals()
     # the truncated L-BFGS amplifies the rounding differences of the two solvers within the frame
     assert it == 12 and np.abs(r - ro).max() < 1e-4 * ro.max() and np.abs(sd - so).max() < 1e-4 * so.max()
+
+
+def test_sparse_and_dense_solve_paths_agree(pkg, monkeypatch):
+    """The same scene through the panel sweeps and through the explicit inverse: the solves agree to rounding
+    (different summation orders), cloth trajectories (no truncated minimiser) to 1e-9."""
+    g = golden("traj_cloth.npz")
+    n = g["x"].shape[0]
+    xs, sol = [], []
+    b = np.random.default_rng(3).normal(size=3 * n)
+    for dm in ("0", "4096"):
+        monkeypatch.setenv("ADMM_HIP_DENSE_MAX", dm)
+        s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
+        s.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
+        s.add_forces(KIND["TRI_STRAIN"], g["tris"], [float(g["k_tri"]), g["lim"][0], g["lim"][1], 1.0])
+        s.add_forces(KIND["BEND"], g["hinges"], [float(g["k_bend"])])
+        s.add_forces(KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
+        s.add_gravity([0, -9.8, 0])
+        s.initialize()
+        assert s.info()["dense_solve"] == (dm != "0")
+        sol.append(s.solve_only(b))
+        for f in range(3):
+            s.step(int(g["iters"]))
+            assert np.abs(s.m_x - g["x_frames"][f]).max() < 1e-9
+        xs.append(s.m_x.copy())
+    assert np.abs(sol[0] - sol[1]).max() < 1e-11 * np.abs(sol[0]).max()
+    assert np.abs(xs[0] - xs[1]).max() < 1e-10
 
 
 def test_graph_replay_matches_eager_launches(pkg, monkeypatch):
