@@ -517,8 +517,8 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     for (int l = 0; l < nl; ++l) {
         const LevelDev &L = ctx->levels[l];
         if (L.n_small) {
-            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + 3) / 4), dim3(256), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
         }
         if (L.n_big) {
             if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);

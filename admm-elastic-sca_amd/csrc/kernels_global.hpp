@@ -242,6 +242,9 @@ __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const 
 #ifndef ADMM_BWD_UNROLL
 #define ADMM_BWD_UNROLL 4         // 64-row groups per load batch in the CW = 1 backward kernel
 #endif
+#ifndef ADMM_FWD_SMALL_WAVES
+#define ADMM_FWD_SMALL_WAVES 4    // wave items per block in the narrow-supernode forward kernel
+#endif
 #ifndef ADMM_BWD_PREFETCH
 #define ADMM_BWD_PREFETCH 1       // CW > 1 backward kernel: first panel rows requested before the staging barrier
 #endif
@@ -253,11 +256,11 @@ constexpr int FWD_SMALL_KMAX = 64;
 // row, the first panel columns) is requested before the staging barrier so that the
 // dependent index -> slot -> value chain overlaps with the panel stream.
 template <bool CG2>
-__global__ __launch_bounds__(256) void solve_fwd_small_kernel(int n_items, const SweepItem *__restrict__ items,
+__global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_kernel(int n_items, const SweepItem *__restrict__ items,
                                                               FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
-    __shared__ double ts[4][FWD_SMALL_KMAX * 3];
+    __shared__ double ts[ADMM_FWD_SMALL_WAVES][FWD_SMALL_KMAX * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + wave;
+    const int item = blockIdx.x * ADMM_FWD_SMALL_WAVES + wave;
     const bool live = item < n_items;
     int tile = 0, k = 0, r = 0, first = 0;
     int64_t foff = 0, poff = 0, soff = 0;

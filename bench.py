@@ -90,11 +90,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # test hooks (1-GPU boxes): ADMM_BENCH_SHARE_GPU=1 puts every rank on cuda:0, ADMM_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("ADMM_BENCH_SHARE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from __graft_entry__ import load_package
     pkg = load_package()
 
@@ -208,7 +215,8 @@ def main():
                                 "tets+tris, %d nodes, %d ADMM iters/frame" % (nx, ny, nz, n_tets, info["n_nodes"], ADMM_ITERS)),
                    "admm_iters_per_step": ADMM_ITERS, "parallelism": "elements sharded x%d, RHS all-reduce, replicated solve" % world,
                    "nnz_L": info["nnz_L"], "supernodes": info["n_supernodes"], "levels": info["n_levels"],
-                   "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"], "host_threads": info["host_threads"]},
+                   "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"], "host_threads": info["host_threads"],
+                   "x_checksum": float(np.abs(xs).sum())},
         "roofline": roof,
     }
     if rank == 0:

@@ -149,3 +149,29 @@ def test_two_shards_on_one_gpu(pkg):
         # = unsharded, up to the order of the fp64 partial sums (first frame: rounding only;
         # later frames: amplified by the truncated prox)
         assert np.abs(x0 - xr).max() < (1e-11 if frame == 0 else 1e-6)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank, all-reduce hook
+    inside the C step loop, barrier + MAX-over-ranks timing, one JSON line from rank 0) -- on a 1-GPU box both ranks share
+    cuda:0 and gloo stands in for RCCL (test hooks of bench.py).  Same final positions as the single-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--steps", "2", "--warmup", "1", "--dims", "6", "6", "20", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                         os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    lines = [l for l in r2.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0 and "cpu_baseline" not in two
+    assert "sharded x2" in two["config"]["parallelism"]
+    # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames (DESIGN.md 4.6)
+    assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-bash tools/bench_variant.sh b64 "-DADMM_LOCAL_BLOCK=64"
-bash tools/bench_variant.sh b256 ""
-bash tools/bench_variant.sh b64 "-DADMM_LOCAL_BLOCK=64"
-bash tools/bench_variant.sh b256 ""
+bash tools/bench_variant.sh w1 "-DADMM_FWD_SMALL_WAVES=1"
+bash tools/bench_variant.sh w4 ""
+bash tools/bench_variant.sh w2 "-DADMM_FWD_SMALL_WAVES=2"
+bash tools/bench_variant.sh w1 "-DADMM_FWD_SMALL_WAVES=1"
