@@ -524,6 +524,36 @@ def test_full_size_properties(pkg):
     assert np.array_equal(xa, xb)
 
 
+def test_full_size_mixed_scene_properties(pkg):
+    """BASELINE.json configs[4] at full size (498,888 NH+StVK tets, 99,856 triangles, 149k hinges, anchors; two
+    disconnected bodies in one factorization): every force kernel in one step -- size-independent properties."""
+    s, d = pkg.make_mixed_system(26, 26, 123, 158, 158)
+    s.initialize()
+    info = s.info()
+    assert info["n_elems_total"] == 498888 + 99856 + d["forces"][3][1].shape[0] + d["forces"][4][1].shape[0]
+    n = s.n_nodes
+    rng = np.random.default_rng(1)
+    b = rng.normal(size=3 * n)
+    x = s.solve_only(b)
+    assert np.abs(s.apply_A(x) - b).max() < 1e-10 * np.abs(b).max()
+    x0 = s.m_x.copy()
+    s.set_gravity(0, [0, 0, 0])
+    s.step(2)
+    assert np.abs(s.m_x - x0).max() < 1e-8                     # rest state is a fixed point for all five kinds (cloth nodes weigh 1e-5 kg: rounding is amplified)
+    s.set_gravity(0, [0, -9.8, 0])
+    s.enable_residuals(True)
+    s.step(20)
+    r, sd, it = s.residuals()
+    assert it == 20 and np.isfinite(r).all() and np.isfinite(sd).all() and r[-1] < r[1]
+    s.enable_residuals(False)
+    s.step(20)
+    x2 = s.m_x.reshape(-1, 3)
+    assert np.isfinite(x2).all()
+    off = d["X"].shape[0] - (159 * 159 + 158 * 158)
+    assert np.abs(x2[off] - d["X"][off]).max() < 1e-4          # cloth corner anchor holds
+    assert x2[off + 159 * 80 + 80, 1] < d["X"][off + 159 * 80 + 80, 1] - 1e-3   # cloth interior falls
+
+
 def test_collision_fixture(pkg):
     """plinkopony-like scene against the compiled reference's trajectory (continuous algorithm: tight)."""
     g = golden("traj_collision.npz")
