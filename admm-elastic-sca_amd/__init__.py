@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libadmm_hip.so")
 
 KIND = dict(ANCHOR=0, SPRING=1, TET_LINEAR=2, TET_VOLUME=3, TET_NH=4, TET_STVK=5, TRI_STRAIN=6, BEND=7, COLLISION=8, TRI_AREA=9, TRI_FUNG=10)
+SHARD = dict(contiguous=0, subtree=1)
 KIND_NODES = [1, 2, 4, 4, 4, 4, 3, 4, 1, 3, 3]
 KIND_ROWS = [3, 3, 9, 9, 9, 9, 6, 9, 3, 6, 6]
 KIND_PARAMS = [2, 1, 1, 3, 3, 3, 4, 1, 1, 4, 3]
@@ -84,6 +85,9 @@ def lib():
         L.admm_hip_destroy.argtypes = [C.c_void_p]
         L.admm_hip_destroy.restype = None
         L.admm_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.admm_hip_set_shard_mode.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_debug_node_owner.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.admm_hip_local_elements.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]
         L.admm_hip_enable_residuals.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_set_tolerance.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
         L.admm_hip_get_residuals.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
@@ -283,16 +287,35 @@ class System:
         self._chk(self.L.admm_hip_get_info(self.h, C.byref(inf)))
         return inf.as_dict()
 
+    def local_elements(self, batch):
+        """this rank's elements of a batch (reference order): the rows of read_local / write_local"""
+        n = C.c_int(0)
+        self._chk(self.L.admm_hip_local_elements(self.h, batch, None, 0, C.byref(n)))
+        ids = np.zeros(n.value, np.int32)
+        self._chk(self.L.admm_hip_local_elements(self.h, batch, _i(ids), n.value, C.byref(n)))
+        return ids
+
     def local_range(self, batch):
-        kind, n = self.batches[batch]
-        inf = self.info()
-        r, w = inf["rank"], inf["world"]
-        return n * r // w, n * (r + 1) // w
+        """contiguous sharding: [first, end) of this rank's elements"""
+        ids = self.local_elements(batch)
+        if ids.size == 0:
+            kind, n = self.batches[batch]
+            inf = self.info()
+            return n * inf["rank"] // inf["world"], n * inf["rank"] // inf["world"]
+        assert np.array_equal(ids, np.arange(ids[0], ids[0] + ids.size)), "not a contiguous shard"
+        return int(ids[0]), int(ids[0]) + ids.size
+
+    def node_owner(self):
+        o = np.zeros(self.n_nodes, np.int32)
+        self._chk(self.L.admm_hip_debug_node_owner(self.h, _i(o)))
+        return o
+
+    def set_shard_mode(self, mode):
+        self._chk(self.L.admm_hip_set_shard_mode(self.h, SHARD[mode] if isinstance(mode, str) else int(mode)))
 
     def read_local(self, batch):
         kind, _ = self.batches[batch]
-        a, b = self.local_range(batch)
-        n = b - a
+        n = self.local_elements(batch).size
         rows = KIND_ROWS[kind]
         u = np.zeros((n, rows)); z = np.zeros((n, rows))
         st = np.zeros((n, 4 if KIND_STATE[kind] else 3)); it = np.zeros(n, np.int32)
@@ -346,7 +369,7 @@ class System:
 
 
 def make_bar_system(nx, ny, nz, kind=KIND["TET_NH"], mu=1e5, lam=1e5, max_iter=5, density=1000.0, h=0.05, dt=0.04,
-                    gravity=(0.0, -9.8, 0.0), device_id=0, rank=0, world=1, stream=None):
+                    gravity=(0.0, -9.8, 0.0), device_id=0, rank=0, world=1, stream=None, shard_mode=None):
     """The synthetic bar of BASELINE.md section 4 config 4: tets first, then
     StaticAnchors on the k = 0 face, gravity, lumped density-weighted mass."""
     x, tets = meshgen.bar(nx, ny, nz, h)
@@ -359,11 +382,13 @@ def make_bar_system(nx, ny, nz, kind=KIND["TET_NH"], mu=1e5, lam=1e5, max_iter=5
     s.add_gravity(gravity)
     if world > 1:
         s.set_shard(rank, world)
+        if shard_mode is not None:
+            s.set_shard_mode(shard_mode)
     s.n_tets = tets.shape[0]
     return s
 
 
-def make_mixed_system(nx, ny, nz, cloth_w, cloth_l, device_id=0, dt=0.04, rank=0, world=1, stream=None):
+def make_mixed_system(nx, ny, nz, cloth_w, cloth_l, device_id=0, dt=0.04, rank=0, world=1, stream=None, shard_mode=None):
     """BASELINE.md section 4 config 5 ("mixed scene"): a bar whose lower half (in z) is Neo-Hookean and
     upper half StVK (tets first), then a sym-plane cloth with LimitedTriangleStrain (k=100,
     limits .95/1.05) + BendForce (k=20) hanging from two corner anchors, bar face anchored, gravity.
@@ -389,5 +414,7 @@ def make_mixed_system(nx, ny, nz, cloth_w, cloth_l, device_id=0, dt=0.04, rank=0
     s.add_gravity((0.0, -9.8, 0.0))
     if world > 1:
         s.set_shard(rank, world)
+        if shard_mode is not None:
+            s.set_shard_mode(shard_mode)
     s.n_elements = tets.shape[0] + tris.shape[0]
     return s, desc

@@ -29,7 +29,8 @@ namespace {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Batch {
-    int kind = 0, n_total = 0, first = 0, n_local = 0;
+    int kind = 0, n_total = 0, n_local = 0;
+    std::vector<int32_t> local;    // this rank's elements (ascending reference order); contiguous range unless subtree sharding
     std::vector<int32_t> idx;      // [n_total][nodes] original ids
     std::vector<double> params;    // [n_total][P]
     std::vector<double> targets;   // anchors [n_total][3]
@@ -97,6 +98,14 @@ struct admm_hip_ctx {
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
+    // subtree sharding (world > 1, ADMM_HIP_SHARD=subtree / admm_hip_set_shard_mode): every rank owns whole subtrees of the
+    // elimination tree and the elements that touch them; only the top of the tree is replicated
+    int shard_mode = 0;                       // 0: contiguous element ranges + replicated solve, 1: subtrees
+    std::vector<int> sn_owner, node_owner;    // -1 = top (replicated); node_owner in factor order
+    std::vector<LevelDev> levels_top;         // sweep items of the top supernodes (levels = this rank's own ones)
+    int n_comm_top = 0, n_comm_slots = 0;
+    int *d_comm_top = nullptr, *d_comm_slots = nullptr; unsigned char *d_comm_mine = nullptr, *d_base_mask = nullptr, *d_keep_mask = nullptr;
+    double *d_comm_buf = nullptr;
     // small systems: explicit inverse of the scalar system (factor order), one kernel per solve
     int dense_max = 2048; bool dense = false; std::vector<double> Ainv; double *d_ainv = nullptr;
     // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
@@ -266,6 +275,88 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
     return ADMM_OK;
 }
 
+// ---- subtree sharding: who owns which supernode ------------------------------------------------------
+// Split the heaviest open subtree at its root (the root joins the replicated top) until there are >= 4 open subtrees per
+// rank, then give the subtrees to the ranks largest first (LPT).  Every vertex separator is a supernode, so an element
+// whose nodes are not all in the top lies inside exactly ONE subtree plus its ancestors: it goes to that subtree's rank.
+void partition_subtrees(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size(), world = ctx->world;
+    ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
+    if (ctx->shard_mode != 1 || world <= 1) return;
+    std::vector<double> weight(ns, 0.0);
+    std::vector<std::vector<int> > kids(ns);
+    for (int s = 0; s < ns; ++s) {   // postorder: children come before parents
+        weight[s] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
+        if (F.sn[s].parent >= 0) { weight[F.sn[s].parent] += weight[s]; kids[F.sn[s].parent].push_back(s); }
+    }
+    std::vector<char> top(ns, 0);
+    auto cmp = [&](int a, int b) { return weight[a] < weight[b] || (weight[a] == weight[b] && a > b); };
+    std::vector<int> open, done;
+    for (int s = 0; s < ns; ++s) if (F.sn[s].parent < 0) open.push_back(s);
+    std::make_heap(open.begin(), open.end(), cmp);
+    // LPT assignment of the current subtrees; returns max load / mean load
+    std::vector<double> load(world, 0.0);
+    std::vector<int> root_owner(ns, -2);
+    auto assign = [&]() {
+        std::vector<int> all(done); all.insert(all.end(), open.begin(), open.end());
+        std::sort(all.begin(), all.end(), [&](int a, int b) { return weight[a] > weight[b] || (weight[a] == weight[b] && a < b); });
+        std::fill(load.begin(), load.end(), 0.0); std::fill(root_owner.begin(), root_owner.end(), -2);
+        double tot = 0.0;
+        for (int s : all) { const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin()); root_owner[s] = r; load[r] += weight[s]; tot += weight[s]; }
+        return tot > 0.0 ? *std::max_element(load.begin(), load.end()) * world / tot : 1.0;
+    };
+    // every split moves a separator into the replicated top: stop as soon as there is one subtree per rank and the loads
+    // balance within 15 %, at the latest at four subtrees per rank
+    while (!open.empty()) {
+        const int have = (int)(open.size() + done.size());
+        if (have >= 4 * world || (have >= world && assign() <= 1.15)) break;
+        std::pop_heap(open.begin(), open.end(), cmp);
+        const int s = open.back(); open.pop_back();
+        if (kids[s].empty()) { done.push_back(s); continue; }
+        top[s] = 1;
+        for (int c : kids[s]) { open.push_back(c); std::push_heap(open.begin(), open.end(), cmp); }
+    }
+    assign();
+    done.insert(done.end(), open.begin(), open.end());
+    for (int s = ns - 1; s >= 0; --s) {   // parents before children
+        if (top[s]) ctx->sn_owner[s] = -1;
+        else if (root_owner[s] != -2) ctx->sn_owner[s] = root_owner[s];
+        else ctx->sn_owner[s] = ctx->sn_owner[F.sn[s].parent];
+    }
+    for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];
+    if (getenv("ADMM_HIP_VERBOSE")) {
+        int nt = 0; for (int s = 0; s < ns; ++s) nt += top[s];
+        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (1e6 entries):", nt, done.size());
+        for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
+        fprintf(stderr, "\n");
+    }
+}
+
+// this rank's elements of every batch
+void assign_elements(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    int64_t nloc = 0;
+    for (Batch &b : ctx->batches) {
+        const int nn = ADMM_KIND_NODES[b.kind];
+        b.local.clear();
+        if (ctx->shard_mode == 1 && ctx->world > 1) {
+            for (int e = 0; e < b.n_total; ++e) {
+                int owner = -1;
+                for (int c = 0; c < nn && owner < 0; ++c) owner = ctx->node_owner[F.iperm[b.idx[(size_t)e * nn + c]]];
+                if (owner < 0) owner = e % ctx->world;      // all nodes in the replicated top: any rank will do
+                if (owner == ctx->rank) b.local.push_back(e);
+            }
+        } else {   // contiguous ranges (reference order preserved inside a rank)
+            const int first = (int)((int64_t)b.n_total * ctx->rank / ctx->world), end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
+            for (int e = first; e < end; ++e) b.local.push_back(e);
+        }
+        b.n_local = (int)b.local.size();
+        nloc += b.n_local;
+    }
+    ctx->info.n_elems_local = nloc;
+}
+
 // ---- device upload ----------------------------------------------------------
 template <class T> std::vector<T> permute_nodes(const std::vector<T> &h, const std::vector<int> &perm, int comps) {
     std::vector<T> o(h.size());
@@ -295,23 +386,48 @@ int upload_factor(admm_hip_ctx *ctx) {
     // a wave item and the backward kernel takes 4 columns per wave; from it upwards block items / ADMM_BWD_BIG_CW.
     int split = (int)F.levels.size();
     for (int l = 0; l < (int)F.levels.size() && split == (int)F.levels.size(); ++l) for (int s : F.levels[l]) if (F.sn[s].ncols > admm_dev::FWD_SMALL_KMAX) { split = l; break; }
-    for (size_t l = 0; l < F.levels.size(); ++l) {
-        LevelDev &L = ctx->levels[l];
-        std::vector<admm_dev::SweepItem> sm, bg, bw;
-        L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
-        for (int s : F.levels[l]) {
-            const Supernode &S = F.sn[s];
-            admm_dev::SweepItem it{};
-            it.s = s; it.k = S.ncols; it.r = S.nrows; it.first = S.first;
-            it.panel_off = S.panel_off; it.front_off = S.front_off; it.slot_off = S.slot_off; it.rows_off = S.rows_off;
-            const int f = S.ncols + S.nrows;
-            const int tiles = (f + 63) / 64;
-            for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
-            const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
-            for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
+    const bool subtree = ctx->shard_mode == 1 && ctx->world > 1;
+    ctx->levels_top.assign(subtree ? F.levels.size() : 0, LevelDev());
+    for (int pass = 0; pass < (subtree ? 2 : 1); ++pass) {      // pass 0: this rank's supernodes (all of them without subtree sharding), pass 1: the replicated top
+        for (size_t l = 0; l < F.levels.size(); ++l) {
+            LevelDev &L = pass == 0 ? ctx->levels[l] : ctx->levels_top[l];
+            std::vector<admm_dev::SweepItem> sm, bg, bw;
+            L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
+            for (int s : F.levels[l]) {
+                if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
+                const Supernode &S = F.sn[s];
+                admm_dev::SweepItem it{};
+                it.s = s; it.k = S.ncols; it.r = S.nrows; it.first = S.first;
+                it.panel_off = S.panel_off; it.front_off = S.front_off; it.slot_off = S.slot_off; it.rows_off = S.rows_off;
+                const int f = S.ncols + S.nrows;
+                const int tiles = (f + 63) / 64;
+                for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
+                const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
+                for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
+            }
+            L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
+            TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
         }
-        L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
-        TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
+    }
+    // subtree sharding: the exchange lists (see shard_pack_kernel) and the node masks
+    ctx->n_comm_top = ctx->n_comm_slots = 0;
+    ctx->d_comm_top = ctx->d_comm_slots = nullptr; ctx->d_comm_mine = ctx->d_base_mask = ctx->d_keep_mask = nullptr; ctx->d_comm_buf = nullptr;
+    if (subtree) {
+        std::vector<int> top_nodes, slots; std::vector<unsigned char> mine, base(F.n), keep(F.n);
+        for (int i = 0; i < F.n; ++i) {
+            const int o = ctx->node_owner[i];
+            if (o < 0) top_nodes.push_back(i);
+            base[i] = keep[i] = (o == ctx->rank || (o < 0 && ctx->rank == 0)) ? 1 : 0;
+        }
+        for (int s = 0; s < ns; ++s) {      // roots of the owned subtrees: their contribution rows feed the top
+            const int par = F.sn[s].parent;
+            if (ctx->sn_owner[s] < 0 || par < 0 || ctx->sn_owner[par] >= 0) continue;
+            for (int q = 0; q < F.sn[s].nrows; ++q) { slots.push_back((int)(F.sn[s].slot_off + q)); mine.push_back(ctx->sn_owner[s] == ctx->rank ? 1 : 0); }
+        }
+        ctx->n_comm_top = (int)top_nodes.size(); ctx->n_comm_slots = (int)slots.size();
+        TRY(upload(ctx, &ctx->d_comm_top, top_nodes)); TRY(upload(ctx, &ctx->d_comm_slots, slots)); TRY(upload(ctx, &ctx->d_comm_mine, mine));
+        TRY(upload(ctx, &ctx->d_base_mask, base)); TRY(upload(ctx, &ctx->d_keep_mask, keep));
+        TRY(dalloc(ctx, &ctx->d_comm_buf, 3 * (size_t)std::max(1, ctx->n_comm_top + ctx->n_comm_slots)));
     }
     return ADMM_OK;
 }
@@ -336,9 +452,6 @@ int upload_all(admm_hip_ctx *ctx) {
     std::vector<int64_t> inc_ptr(n + 1, 0);
     for (Batch &b : ctx->batches) {
         const int nn = ADMM_KIND_NODES[b.kind];
-        b.first = (int)((int64_t)b.n_total * ctx->rank / ctx->world);
-        const int end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
-        b.n_local = end - b.first;
         b.slot_base = slot;
         const bool is_tri = b.kind == ADMM_KIND_TRI_STRAIN || b.kind == ADMM_KIND_TRI_AREA || b.kind == ADMM_KIND_TRI_FUNG;
         const bool sort_corners = (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) || is_tri;
@@ -347,7 +460,7 @@ int upload_all(admm_hip_ctx *ctx) {
             for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
         b.corner_perm.assign((size_t)b.n_total * nn, 0);
         for (int el = 0; el < b.n_local; ++el) {
-            const int e = b.first + el;
+            const int e = b.local[el];
             const int *id = b.idx.data() + (size_t)e * nn;
             int ord[4] = {0, 1, 2, 3};
             if (sort_corners) std::stable_sort(ord, ord + nn, [&](int a, int c) { return id[a] < id[c]; });
@@ -365,7 +478,7 @@ int upload_all(admm_hip_ctx *ctx) {
         b.G.assign((size_t)12 * std::max(nl, 1), 0.0);
         std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
         for (int el = 0; el < nl; ++el) {
-            const int e = b.first + el;
+            const int e = b.local[el];
             const int *id = b.idx.data() + (size_t)e * nn;
             const int *ord = b.corner_perm.data() + (size_t)e * nn;
             for (int c = 0; c < nn; ++c) {
@@ -403,7 +516,7 @@ int upload_all(admm_hip_ctx *ctx) {
         HIPCHK(hipMemset(b.d_niters, 0, sizeof(int) * (size_t)std::max(nl, 1)));
         if (b.kind == ADMM_KIND_ANCHOR) {
             std::vector<double> tg((size_t)3 * std::max(nl, 1), 0.0); std::vector<int> ac(std::max(nl, 1), 1);
-            for (int el = 0; el < nl; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)(b.first + el) + j]; ac[el] = b.active[b.first + el]; }
+            for (int el = 0; el < nl; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)b.local[el] + j]; ac[el] = b.active[b.local[el]]; }
             TRY(upload(ctx, &b.d_targets, tg)); TRY(upload(ctx, &b.d_active, ac));
         }
     }
@@ -498,7 +611,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
 int launch_rhs(admm_hip_ctx *ctx) {
     const int n3 = 3 * ctx->n_nodes;
     hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr,
-                       ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, ctx->d_y);
+                       ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, (const unsigned char *)ctx->d_base_mask, ctx->d_y);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -513,30 +626,61 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
         return ADMM_OK;
     }
     const FactorDev F = factor_dev(ctx);
-    const int nl = (int)ctx->levels.size();
-    for (int l = 0; l < nl; ++l) {
-        const LevelDev &L = ctx->levels[l];
-        if (L.n_small) {
-            if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+    auto forward = [&](const std::vector<LevelDev> &levels) {
+        for (const LevelDev &L : levels) {
+            if (L.n_small) {
+                if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            }
+            if (L.n_big) {
+                if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
+            }
         }
-        if (L.n_big) {
-            if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
-            else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
-        }
-    }
-    if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
-    for (int l = nl - 1; l >= 0; --l) {
-        const LevelDev &L = ctx->levels[l];
-        if (L.n_bwd) {
+    };
+    auto backward = [&](const std::vector<LevelDev> &levels) {
+        for (int l = (int)levels.size() - 1; l >= 0; --l) {
+            const LevelDev &L = levels[l];
+            if (!L.n_bwd) continue;
             if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
         }
+    };
+    forward(ctx->levels);
+    if (!ctx->levels_top.empty()) {
+        // subtree sharding: own subtrees are done; ONE small all-reduce carries the top nodes' partial right-hand sides and the
+        // subtree roots' contributions to every rank, then everybody runs the (replicated) top of the tree
+        const int n = ctx->n_comm_top + ctx->n_comm_slots;
+        if (n > 0) {
+            hipLaunchKernelGGL(shard_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
+                               (const int *)ctx->d_comm_slots, (const unsigned char *)ctx->d_comm_mine, (const double *)ctx->d_y, (const double *)ctx->d_c, ctx->d_comm_buf);
+            if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
+            if (ctx->allreduce(ctx->allreduce_user, ctx->d_comm_buf, 3 * (int64_t)n, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+            hipLaunchKernelGGL(shard_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
+                               (const int *)ctx->d_comm_slots, (const double *)ctx->d_comm_buf, ctx->d_y, ctx->d_c);
+        }
+        forward(ctx->levels_top);
     }
+    if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
+    if (!ctx->levels_top.empty()) backward(ctx->levels_top);
+    backward(ctx->levels);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
+
+// subtree sharding: after the solve a rank holds x only on its own subtrees and the top; rebuild the full vector
+// (once per frame, and for the solve-only entry point)
+int shard_sync_x(admm_hip_ctx *ctx) {
+    if (ctx->levels_top.empty()) return ADMM_OK;
+    const int n3 = 3 * ctx->n_nodes;
+    hipLaunchKernelGGL(admm_dev::shard_mask_nodes_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const unsigned char *)ctx->d_keep_mask, ctx->d_xcur);
+    if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
+    if (ctx->allreduce(ctx->allreduce_user, ctx->d_xcur, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
 
 // ---- residual tracking (opt-in): buffers are created on first use -------------------------------------
 int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
@@ -590,7 +734,7 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
         first = false;
     }
     if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_res_slots, ctx->d_mxbar, 0, ctx->d_res_s);
+    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
     if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
         if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
         if (ctx->allreduce(ctx->allreduce_user, ctx->d_res_s, (int64_t)n3, (void *)ctx->stream) != 0 || ctx->allreduce(ctx->allreduce_user, r2, 1, (void *)ctx->stream) != 0)
@@ -753,6 +897,24 @@ int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world) {
     ctx->rank = rank; ctx->world = world;
     return ADMM_OK;
 }
+int admm_hip_set_shard_mode(admm_hip_ctx *ctx, int mode) {
+    if (!ctx || (mode != ADMM_SHARD_CONTIGUOUS && mode != ADMM_SHARD_SUBTREE)) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "shard mode must be set before finalize");
+    ctx->shard_mode = mode;
+    return ADMM_OK;
+}
+int admm_hip_local_elements(admm_hip_ctx *ctx, int batch, int32_t *ids, int capacity, int *n_local) {
+    if (!ctx || !ctx->finalized || batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
+    const Batch &b = ctx->batches[batch];
+    if (n_local) *n_local = b.n_local;
+    if (ids) { if (capacity < b.n_local) return ADMM_ERR_ARG; std::copy(b.local.begin(), b.local.end(), ids); }
+    return ADMM_OK;
+}
+int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
+    if (!ctx || !ctx->finalized || !owner) return ADMM_ERR_ARG;
+    for (int i = 0; i < ctx->n_nodes; ++i) owner[i] = (ctx->shard_mode == ADMM_SHARD_SUBTREE && ctx->world > 1) ? ctx->node_owner[ctx->F.iperm[i]] : 0;
+    return ADMM_OK;
+}
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->allreduce = fn; ctx->allreduce_user = user;
@@ -769,15 +931,10 @@ int admm_hip_finalize(admm_hip_ctx *ctx) {
     TRY(host_assemble(ctx, false));
     TRY(host_factor(ctx, false));
     ctx->info.rank = ctx->rank; ctx->info.world = ctx->world;
-    {   // contiguous element ranges per batch (reference order preserved inside a rank)
-        int64_t nloc = 0;
-        for (Batch &b : ctx->batches) {
-            b.first = (int)((int64_t)b.n_total * ctx->rank / ctx->world);
-            b.n_local = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world) - b.first;
-            nloc += b.n_local;
-        }
-        ctx->info.n_elems_local = nloc;
-    }
+    if (const char *e = getenv("ADMM_HIP_SHARD")) ctx->shard_mode = (std::string(e) == "subtree") ? ADMM_SHARD_SUBTREE : ADMM_SHARD_CONTIGUOUS;
+    if (ctx->dense) ctx->shard_mode = 0;          // small systems: one-kernel solve, nothing to shard
+    partition_subtrees(ctx);
+    assign_elements(ctx);
     if (ctx->device_id >= 0) TRY(upload_all(ctx));
     ctx->finalized = true;
     return ADMM_OK;
@@ -803,7 +960,7 @@ int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
         for (Batch &b : ctx->batches) {
             const int nl = b.n_local;
             std::vector<double> w2h2(std::max(nl, 1)), w2(std::max(nl, 1));
-            for (int el = 0; el < nl; ++el) { const double w = b.weight[b.first + el]; w2[el] = w * w; w2h2[el] = (ctx->dt * ctx->dt) * (w * w); }
+            for (int el = 0; el < nl; ++el) { const double w = b.weight[b.local[el]]; w2[el] = w * w; w2h2[el] = (ctx->dt * ctx->dt) * (w * w); }
             if (nl) { HIPCHK(hipMemcpy(b.d_w2h2, w2h2.data(), sizeof(double) * nl, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(b.d_w2, w2.data(), sizeof(double) * nl, hipMemcpyHostToDevice)); }
         }
     }
@@ -818,8 +975,11 @@ int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets,
     if (active) std::copy(active, active + b.n_total, b.active.begin());
     if (ctx->finalized && ctx->device_id >= 0 && b.n_local) {
         HIPCHK(hipSetDevice(ctx->device_id));
-        if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, b.targets.data() + 3 * (size_t)b.first, sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
-        if (active) HIPCHK(hipMemcpyAsync(b.d_active, b.active.data() + b.first, sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        std::vector<double> tg(3 * (size_t)b.n_local); std::vector<int32_t> ac(b.n_local);
+        for (int el = 0; el < b.n_local; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)b.local[el] + j]; ac[el] = b.active[b.local[el]]; }
+        if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, tg.data(), sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        if (active) HIPCHK(hipMemcpyAsync(b.d_active, ac.data(), sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     return ADMM_OK;
@@ -881,7 +1041,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         if (track) { TRY(launch_residuals(ctx, it)); ctx->res_n = it + 1; }
         TRY(launch_rhs(ctx));
         TRY(mark(ctx));
-        if (ctx->world > 1) {
+        if (ctx->world > 1 && ctx->levels_top.empty()) {     // contiguous sharding: the whole RHS is summed, the solve is replicated
             if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
             if (ctx->allreduce(ctx->allreduce_user, ctx->d_y, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
         }
@@ -902,6 +1062,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         }
     }
     ctx->ev_iters = iters_done;
+    TRY(shard_sync_x(ctx));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
     HIPCHK(hipGetLastError());
     TRY(mark(ctx));
@@ -1047,7 +1208,10 @@ int admm_hip_solve_only(admm_hip_ctx *ctx, const double *b, double *x) {
     TRY(require_device(ctx));
     if (!b || !x) return ADMM_ERR_ARG;
     TRY(set_nodes(ctx, ctx->d_y, b));
+    if (!ctx->levels_top.empty())   // subtree sharding sums the top rows over the ranks: every rank was handed the whole b, keep it once
+        hipLaunchKernelGGL(admm_dev::shard_mask_nodes_kernel, dim3((3 * ctx->n_nodes + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const unsigned char *)ctx->d_keep_mask, ctx->d_y);
     TRY(launch_solve(ctx, nullptr));
+    TRY(shard_sync_x(ctx));
     return get_nodes(ctx, ctx->d_xcur, x);
 }
 

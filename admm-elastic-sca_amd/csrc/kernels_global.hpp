@@ -109,16 +109,46 @@ __global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, dou
 // contributions.  The local kernels write every corner's 24 bytes straight to
 // its position in the node's incidence list (node-sorted slots), so this is a
 // contiguous streaming read in fixed (batch, element, corner) order.
-// base = M x_bar on rank 0, 0 elsewhere (the cross-rank sum is the full RHS).
+// base = M x_bar exactly once across ranks: on rank 0 (contiguous sharding: add_base), or where base_mask says this
+// rank is responsible for the node (subtree sharding: the owner of the node's subtree; rank 0 for the replicated top).
 __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr,
-                                  const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base, double *__restrict__ y) {
+                                  const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base,
+                                  const unsigned char *__restrict__ base_mask, double *__restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * n_nodes) return;
     const int node = i / 3, c = i - 3 * node;
     double acc = 0.0;
     const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
     for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
-    y[i] = add_base ? (mxbar[i] + acc) : acc;
+    const bool base = base_mask ? (base_mask[node] != 0) : (add_base != 0);
+    y[i] = base ? (mxbar[i] + acc) : acc;
+}
+
+// ---- subtree sharding of the solve (one process per GPU): the exchange between a rank's own subtrees and the replicated
+// ---- top of the elimination tree is ONE small all-reduce per ADMM iteration over this packed buffer:
+// ----   [ y on the top nodes (partial sums of every rank) | the contribution slots of every subtree root (owner's values, 0 elsewhere) ]
+__global__ void shard_pack_kernel(int n_top, const int *__restrict__ top_nodes, int n_slots, const int *__restrict__ slots, const unsigned char *__restrict__ slot_mine,
+                                  const double *__restrict__ y, const double *__restrict__ C, double *__restrict__ buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_top) { const double *s = y + 3 * (size_t)top_nodes[i]; double *d = buf + 3 * (size_t)i; d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+    else if (i < n_top + n_slots) {
+        const int j = i - n_top;
+        double *d = buf + 3 * (size_t)i;
+        if (slot_mine[j]) { const double *s = C + 3 * (size_t)slots[j]; d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+        else { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; }
+    }
+}
+__global__ void shard_unpack_kernel(int n_top, const int *__restrict__ top_nodes, int n_slots, const int *__restrict__ slots,
+                                    const double *__restrict__ buf, double *__restrict__ y, double *__restrict__ C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_top) { double *d = y + 3 * (size_t)top_nodes[i]; const double *s = buf + 3 * (size_t)i; d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+    else if (i < n_top + n_slots) { double *d = C + 3 * (size_t)slots[i - n_top]; const double *s = buf + 3 * (size_t)i; d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+}
+// x is valid on a rank only where it solved: zero the rest before the once-per-frame all-reduce that rebuilds the full vector
+__global__ void shard_mask_nodes_kernel(int n_nodes, const unsigned char *__restrict__ keep, double *__restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_nodes) return;
+    if (!keep[i / 3]) x[i] = 0.0;
 }
 
 // ---------------------------------------------------------------------------

@@ -100,6 +100,19 @@ int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t
 typedef int (*admm_hip_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *hip_stream);
 int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world);
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user);
+/* How the work is split across the ranks (before finalize; env ADMM_HIP_SHARD=contiguous|subtree overrides):
+ *   ADMM_SHARD_CONTIGUOUS  every batch is cut into `world` contiguous element ranges; per ADMM iteration the whole right-hand
+ *                          side (3 n doubles) is all-reduced and every rank runs the complete solve.
+ *   ADMM_SHARD_SUBTREE     the elimination tree is cut below its top: every rank owns whole subtrees and the elements touching
+ *                          them (an element's nodes lie in one subtree plus separators above it); per iteration ONE small
+ *                          all-reduce carries the top separators' partial right-hand sides and the subtree roots' contributions,
+ *                          only the top levels of the solve are replicated, and the full x is rebuilt once per frame.
+ * admm_hip_local_elements: this rank's elements of a batch (ascending reference order) -- the order of read_local / write_local. */
+enum { ADMM_SHARD_CONTIGUOUS = 0, ADMM_SHARD_SUBTREE = 1 };
+int admm_hip_set_shard_mode(admm_hip_ctx *ctx, int mode);
+int admm_hip_local_elements(admm_hip_ctx *ctx, int batch, int32_t *ids, int capacity, int *n_local);
+/* test hook: the rank that owns each node's subtree (original node order), -1 = replicated top; 0 everywhere without subtree sharding */
+int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner);
 
 /* ---- initialize -----------------------------------------------------------
  * replaces: System::initialize()                          (System.cpp:98-156)

@@ -102,6 +102,139 @@ def test_world_without_hook_is_an_error(pkg):
         s.set_shard(0, 2)          # too late
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_subtree_partition_properties(pkg, monkeypatch, world):
+    """Subtree sharding, host side: the ranks' element sets partition every batch; every node an element touches is
+    owned by that element's rank or lies in the replicated top; the top is a small part of the nodes; the loads balance."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")          # (small systems are solved with the explicit inverse and never sharded)
+    dims = (6, 6, 40)
+    mg = pkg.meshgen
+    x, t = mg.bar(*dims)
+    systems = []
+    for r in range(world):
+        s = pkg.make_bar_system(*dims, device_id=-1, rank=r, world=world)
+        s.set_shard_mode("subtree")
+        s.initialize()
+        systems.append(s)
+    owner = systems[0].node_owner()
+    for s in systems[1:]:
+        assert np.array_equal(s.node_owner(), owner)                     # every rank computes the same partition
+    assert owner.min() == -1 and owner.max() == world - 1
+    assert (owner == -1).mean() < 0.35
+    anchors = mg.bar_anchor_nodes(dims[0], dims[1])
+    for b, idx in enumerate((t, anchors.reshape(-1, 1))):
+        seen = np.zeros(idx.shape[0], np.int32)
+        for r, s in enumerate(systems):
+            ids = s.local_elements(b)
+            assert np.all(np.diff(ids) > 0)                              # reference order inside a rank
+            seen[ids] += 1
+            o = owner[idx[ids]]
+            assert np.all((o == r) | (o == -1)), (b, r)
+        assert np.all(seen == 1)
+    loads = np.array([s.info()["n_elems_local"] for s in systems], dtype=float)
+    assert loads.sum() == t.shape[0] + anchors.size and loads.max() < 1.6 * loads.mean()
+
+
+def _thread_allreduce_hooks(world):
+    """all-reduce between `world` contexts living in ONE process on ONE GPU (threads meeting at barriers)"""
+    import torch
+    bar = threading.Barrier(world)
+    bufs = {}
+
+    class _Ptr:
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def make_hook(r):
+        def hook(ptr, count, stream):
+            torch.cuda.synchronize()
+            bufs[r] = torch.as_tensor(_Ptr(ptr, count), device="cuda:0")
+            bar.wait()
+            if r == 0:
+                tot = bufs[0].clone()
+                for q in range(1, world):
+                    tot += bufs[q]
+                for q in range(world):
+                    bufs[q].copy_(tot)
+                torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        return hook
+    return [make_hook(r) for r in range(world)]
+
+
+def _run_sharded(shards, frames, iters, b):
+    world = len(shards)
+    out = [None] * world
+    errs = []
+
+    def run(r):
+        try:
+            sol = shards[r].solve_only(b)
+            xs = []
+            for _ in range(frames):
+                shards[r].step(iters)
+                xs.append(shards[r].m_x.copy())
+            out[r] = (sol, xs, shards[r].m_v.copy())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+            raise
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "subtree"), (4, "subtree"), (3, "subtree"), (8, "subtree"), (4, "contiguous")])
+def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
+    """`world` shards of one scene on ONE GPU (one context and one host thread per rank, meeting in the all-reduce hook)
+    against the unsharded step, plus the solve-only entry point.  Subtree sharding exchanges only the top separators' rows
+    per iteration and rebuilds x once per frame.  Cloth (triangle strain + bend + anchors: no truncated minimiser): tight.
+    StVK bar: the sums meet in another order and the truncated L-BFGS amplifies that: 1e-5 over 3 frames."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")          # the panel sweeps, not the small-system inverse
+    from conftest import golden
+    g = golden("traj_cloth.npz")
+    n = g["x"].shape[0]
+
+    def cloth(rank, w):
+        s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
+        s.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
+        s.add_forces(pkg.KIND["TRI_STRAIN"], g["tris"], [float(g["k_tri"]), g["lim"][0], g["lim"][1], 1.0])
+        s.add_forces(pkg.KIND["BEND"], g["hinges"], [float(g["k_bend"])])
+        s.add_forces(pkg.KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
+        s.add_gravity([0, -9.8, 0])
+        if w > 1:
+            s.set_shard(rank, w)
+        return s
+    dims = (5, 4, 30)
+    for name, make, tol in (("cloth", cloth, 1e-9), ("bar", lambda r, w: pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=w), 1e-5)):
+        ref = make(0, 1)
+        ref.initialize()
+        shards = [make(r, world) for r in range(world)]
+        hooks = _thread_allreduce_hooks(world)
+        for r, s in enumerate(shards):
+            s.set_shard_mode(mode)
+            s.set_allreduce(hooks[r])
+            s.initialize()
+        assert sum(s.info()["n_elems_local"] for s in shards) == ref.info()["n_elems_total"]
+        b = np.random.default_rng(2).normal(size=3 * ref.n_nodes)
+        xref = ref.solve_only(b)
+        out = _run_sharded(shards, 3, 10, b)
+        refx = []
+        for _ in range(3):
+            ref.step(10); refx.append(ref.m_x.copy())
+        for r in range(world):
+            sol, xs, vs = out[r]
+            assert np.abs(sol - xref).max() < 1e-10 * np.abs(xref).max(), (name, r, "solve")
+            for f in range(3):
+                assert np.abs(xs[f] - refx[f]).max() < tol, (name, r, f, np.abs(xs[f] - refx[f]).max())
+            assert np.array_equal(xs[-1], out[0][1][-1]) and np.array_equal(vs, out[0][2])      # all ranks end bitwise identical
+
+
 @pytest.mark.gpu
 def test_two_shards_on_one_gpu(pkg):
     import torch
@@ -160,7 +293,7 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = ["--steps", "2", "--warmup", "1", "--dims", "6", "6", "20", "--no-cpu-baseline"]
+    args = ["--steps", "2", "--warmup", "1", "--dims", "8", "8", "40", "--no-cpu-baseline"]      # 3321 nodes: the panel sweeps, sharded by subtree
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     one = json.loads(r1.stdout.strip().splitlines()[-1])
@@ -172,6 +305,6 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert len(lines) == 1                                    # rank 0 only
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0 and "cpu_baseline" not in two
-    assert "sharded x2" in two["config"]["parallelism"]
+    assert two["config"]["parallelism"].startswith("x2: elements and elimination subtrees")
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
