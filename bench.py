@@ -97,7 +97,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # test hooks (1-GPU boxes): ADMM_BENCH_SHARE_GPU=1 puts every rank on cuda:0, ADMM_BENCH_BACKEND=gloo replaces RCCL
+    # test hooks (1-GPU boxes): ADMM_BENCH_SHARE_GPU=1 puts every rank on cuda:0, ADMM_BENCH_BACKEND=gloo replaces RCCL;
+    # ADMM_BENCH_FAKE_WORLD=N (with BENCH_TIMING_EXPERIMENT=1): time ONE rank's kernels of an N-rank run with a no-op all-reduce
+    # (wrong numbers, right launch sequence) -- what a rank computes per iteration, communication excluded
+    fake_world = int(os.environ.get("ADMM_BENCH_FAKE_WORLD", "0"))
     if os.environ.get("ADMM_BENCH_SHARE_GPU"):
         local_rank = 0
     backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
@@ -122,7 +125,11 @@ def main():
         s.n_tets = s.n_elements
         a.no_cpu_baseline = True
     else:
-        s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=rank, world=world, stream=stream.cuda_stream, shard_mode=a.shard)
+        s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0")) if fake_world > 1 else rank,
+                                world=fake_world if fake_world > 1 else world, stream=stream.cuda_stream, shard_mode=a.shard)
+    if fake_world > 1:
+        s_fake_rank = int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0"))
+        s.set_allreduce(lambda ptr, count, strm: 0)
     if world > 1:
         n3 = None
         holder = {}
