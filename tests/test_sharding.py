@@ -211,7 +211,10 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
             s.set_shard(rank, w)
         return s
     dims = (5, 4, 30)
-    for name, make, tol in (("cloth", cloth, 1e-9), ("bar", lambda r, w: pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=w), 1e-5)):
+    def mixed(rank, w):     # two disconnected bodies (two elimination-tree roots), five force kinds
+        return pkg.make_mixed_system(4, 3, 12, 10, 8, rank=rank, world=w)[0]
+    for name, make, tol in (("cloth", cloth, 1e-9), ("bar", lambda r, w: pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=w), 1e-5),
+                            ("mixed", mixed, 1e-5)):
         ref = make(0, 1)
         ref.initialize()
         shards = [make(r, world) for r in range(world)]
