@@ -192,6 +192,8 @@ def main():
         "solve_fwd (gather+panel kernels, all levels)": (panel_bytes, fwd_s),
         "solve_bwd_kernel (all levels)": (panel_bytes, bwd_s),
     }
+    if world > 1 and a.shard == "subtree":      # a rank streams only its own subtrees' panels + the top: no per-rank byte count is kept
+        cands = {k: v for k, v in cands.items() if k.startswith("project_tet_kernel")}
     dom = max(cands, key=lambda k: cands[k][1])
     by, sec = cands[dom]
     ach = by / sec / 1e9 if sec > 0 else 0.0
