@@ -79,7 +79,7 @@ struct admm_hip_ctx {
     int rank = 0, world = 1;
     admm_hip_allreduce_fn allreduce = nullptr; void *allreduce_user = nullptr;
     bool finalized = false;
-    int leaf_size = 16;
+    int leaf_size = 0;                        // nested-dissection leaf size; 0 = by system size (host_factor)
     // host state
     int n_nodes = 0;
     std::vector<double> x, v, m3;
@@ -234,7 +234,11 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
     ctx->info.host_threads = threads;
     if (!reuse_symbolic) {
         std::vector<double> xyz(ctx->x);
-        analyze(ctx->A, xyz.data(), ctx->leaf_size, ctx->F);
+        // Larger dissection leaves = fewer elimination-tree levels (each costs >= 7-10 us per sweep whatever its size) for a little
+        // more fill.  Measured (tools/leaf_sweep.py, us per ADMM iteration, leaf 16 / 64 / 128 / 256): 18.8k nodes 266 / 251 / 235 / 229,
+        // 44k nodes 334 / 318 / 321 / 322, 178.6k nodes 982 / 954 / 1026 / 1020.
+        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->n_nodes < 25000 ? 256 : 64);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F);
     }
     int err = factorize(ctx->A, ctx->F, threads);
     if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);

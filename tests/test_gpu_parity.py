@@ -225,10 +225,12 @@ def _bar_pair(pkg, kind, dims, iters):
     return s, o
 
 
-@pytest.mark.parametrize("dense_max", ["0", "2048"])
-def test_solve_residual_and_vs_oracle(pkg, monkeypatch, dense_max):
-    """both solve paths: the supernodal panel sweeps (dense_max 0) and, for small systems, x = A^-1 b with the explicit inverse"""
+@pytest.mark.parametrize("dense_max,leaf", [("0", "16"), ("0", "0"), ("2048", "0")])
+def test_solve_residual_and_vs_oracle(pkg, monkeypatch, dense_max, leaf):
+    """both solve paths: the supernodal panel sweeps (dense_max 0; leaf 16 = deep tree of narrow supernodes, wave items; leaf 0 =
+    automatic, here 256: wide supernodes, block items) and, for small systems, x = A^-1 b with the explicit inverse"""
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", dense_max)
+    monkeypatch.setenv("ADMM_HIP_LEAF", leaf)
     s, o = _bar_pair(pkg, KIND["TET_NH"], (6, 5, 17), 1)
     n = s.n_nodes
     assert s.info()["dense_solve"] == (1 if dense_max != "0" else 0)

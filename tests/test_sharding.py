@@ -107,6 +107,7 @@ def test_subtree_partition_properties(pkg, monkeypatch, world):
     """Subtree sharding, host side: the ranks' element sets partition every batch; every node an element touches is
     owned by that element's rank or lies in the replicated top; the top is a small part of the nodes; the loads balance."""
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")          # (small systems are solved with the explicit inverse and never sharded)
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")              # a deep elimination tree on a small mesh
     dims = (6, 6, 40)
     mg = pkg.meshgen
     x, t = mg.bar(*dims)
@@ -196,6 +197,7 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
     per iteration and rebuilds x once per frame.  Cloth (triangle strain + bend + anchors: no truncated minimiser): tight.
     StVK bar: the sums meet in another order and the truncated L-BFGS amplifies that: 1e-5 over 3 frames."""
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")          # the panel sweeps, not the small-system inverse
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")              # a deep elimination tree on a small mesh
     from conftest import golden
     g = golden("traj_cloth.npz")
     n = g["x"].shape[0]
