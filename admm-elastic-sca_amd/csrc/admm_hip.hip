@@ -94,7 +94,7 @@ struct admm_hip_ctx {
     double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
     double *d_fslot = nullptr; int64_t n_fslots = 0;
     int64_t *d_inc_ptr = nullptr;
-    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr, *d_cg2 = nullptr;
+    double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr, *d_cg4 = nullptr;
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
     std::vector<LevelDev> levels;
     std::vector<void *> allocs;
@@ -238,7 +238,11 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // more fill.  Measured (tools/leaf_sweep.py, us per ADMM iteration, leaf 16 / 64 / 128 / 256): 18.8k nodes 266 / 251 / 235 / 229,
         // 44k nodes 334 / 318 / 321 / 322, 178.6k nodes 982 / 954 / 1026 / 1020.
         const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->n_nodes < 25000 ? 256 : 64);
-        analyze(ctx->A, xyz.data(), leaf, ctx->F);
+        // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
+        // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
+        int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
+        if (const char *e = getenv("ADMM_HIP_MERGE")) merge_above = atoi(e);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above);
     }
     int err = factorize(ctx->A, ctx->F, threads);
     if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
@@ -380,8 +384,8 @@ int upload_factor(admm_hip_ctx *ctx) {
     TRY(upload(ctx, &ctx->d_rows, F.rows));
     TRY(upload(ctx, &ctx->d_sn_front_off, foff));
     TRY(upload(ctx, &ctx->d_cg_ptr, F.cg_ptr)); TRY(upload(ctx, &ctx->d_cg_slot, F.cg_slot));
-    ctx->d_cg2 = nullptr;
-    if (!F.cg2.empty()) TRY(upload(ctx, &ctx->d_cg2, F.cg2));
+    ctx->d_cg4 = nullptr;
+    if (!F.cg4.empty()) TRY(upload(ctx, &ctx->d_cg4, F.cg4));
     TRY(dalloc(ctx, &ctx->d_c, 3 * (size_t)std::max<int64_t>(F.n_slots, 1)));
     ctx->d_ainv = nullptr;
     if (ctx->dense) TRY(upload(ctx, &ctx->d_ainv, ctx->Ainv));
@@ -571,7 +575,7 @@ FactorDev factor_dev(const admm_hip_ctx *ctx) {
     FactorDev f{};
     f.panels = ctx->d_panels; f.sn_first = ctx->d_sn_first; f.sn_ncols = ctx->d_sn_ncols; f.sn_nrows = ctx->d_sn_nrows;
     f.sn_panel_off = ctx->d_sn_panel_off; f.sn_rows_off = ctx->d_sn_rows_off; f.sn_slot_off = ctx->d_sn_slot_off;
-    f.rows = ctx->d_rows; f.sn_front_off = ctx->d_sn_front_off; f.cg_ptr = ctx->d_cg_ptr; f.cg_slot = ctx->d_cg_slot; f.cg2 = (const int2 *)ctx->d_cg2;
+    f.rows = ctx->d_rows; f.sn_front_off = ctx->d_sn_front_off; f.cg_ptr = ctx->d_cg_ptr; f.cg_slot = ctx->d_cg_slot; f.cg4 = (const int4 *)ctx->d_cg4;
     return f;
 }
 
@@ -633,11 +637,11 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
     auto forward = [&](const std::vector<LevelDev> &levels) {
         for (const LevelDev &L : levels) {
             if (L.n_small) {
-                if (F.cg2) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                if (F.cg4) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
                 else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
             if (L.n_big) {
-                if (F.cg2) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
                 else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
         }

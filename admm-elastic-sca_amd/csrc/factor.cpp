@@ -77,9 +77,10 @@ struct ND {
         return (int)sn.size() - 1;
     }
 
-    int rec(std::vector<int> &nodes) {
+    // One bisection: median split of `nodes` along their longest axis; the smaller of the two boundary sets becomes the
+    // separator.  L, R: the two sides without the separator; sep sorted along the axis.
+    void bisect(std::vector<int> &nodes, std::vector<int> &L, std::vector<int> &R, std::vector<int> &sepc) {
         const int m = (int)nodes.size();
-        if (m <= leaf) return emit(nodes);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int v : nodes) for (int c = 0; c < 3; ++c) { double q = xyz[3 * (size_t)v + c]; lo[c] = std::min(lo[c], q); hi[c] = std::max(hi[c], q); }
         int ax = 0; double ext = hi[0] - lo[0];
@@ -102,24 +103,49 @@ struct ND {
         if (sep.empty()) sep.push_back(nodes[m - 1]); // disconnected halves: any node roots the subtree
         const int ts = next_tag++;
         for (int v : sep) tag[v] = ts;
-        std::vector<int> L, R;
+        L.clear(); R.clear();
         L.reserve(half); R.reserve(m - half);
         for (int i = 0; i < m; ++i) { int v = nodes[i]; if (tag[v] == tl) L.push_back(v); else if (tag[v] == tr) R.push_back(v); }
-        std::vector<int> sepc(sep);
+        sepc = sep;
         std::sort(sepc.begin(), sepc.end(), cmp);
         { std::vector<int>().swap(nodes); }
-        int cl = -1, cr = -1;
-        if (!L.empty()) cl = rec(L);
-        if (!R.empty()) cr = rec(R);
-        int s = emit(sepc);
-        if (cl >= 0) sn[cl].parent = s;
-        if (cr >= 0) sn[cr].parent = s;
+    }
+
+    // Regions of more than `merge` nodes become FOUR-way tree nodes: the region's separator and the separators of its two
+    // halves form one (dense) supernode with the four quarters as children -- half as many elimination-tree levels for the
+    // zero blocks between the two half-separators.
+    int merge = 0;
+    int rec(std::vector<int> &nodes) {
+        const int m = (int)nodes.size();
+        if (m <= leaf) return emit(nodes);
+        const bool four = merge > 0 && m > merge;
+        std::vector<int> L, R, sep;
+        bisect(nodes, L, R, sep);
+        std::vector<int> kids;
+        std::vector<int> cols;
+        if (four) {
+            for (std::vector<int> *H : {&L, &R}) {
+                if (H->empty()) continue;
+                if ((int)H->size() <= leaf) { kids.push_back(rec(*H)); continue; }
+                std::vector<int> a, b, sh;
+                bisect(*H, a, b, sh);
+                if (!a.empty()) kids.push_back(rec(a));
+                if (!b.empty()) kids.push_back(rec(b));
+                cols.insert(cols.end(), sh.begin(), sh.end());
+            }
+        } else {
+            if (!L.empty()) kids.push_back(rec(L));
+            if (!R.empty()) kids.push_back(rec(R));
+        }
+        cols.insert(cols.end(), sep.begin(), sep.end());
+        const int s = emit(cols);
+        for (int c : kids) sn[c].parent = s;
         return s;
     }
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -133,7 +159,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F) {
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size);
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
@@ -212,12 +238,12 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F) {
             if (C.parent < 0) continue;
             for (int q = 0; q < C.nrows; ++q) F.cg_slot[pos[target[C.rows_off + q]]++] = (int)(C.slot_off + q);
         }
-        bool two = true;
-        for (int64_t i = 0; i < foff && two; ++i) two = (F.cg_ptr[i + 1] - F.cg_ptr[i]) <= 2;
-        F.cg2.clear();
-        if (two) {
-            F.cg2.assign(2 * (size_t)foff, -1);
-            for (int64_t i = 0; i < foff; ++i) for (int64_t g = F.cg_ptr[i]; g < F.cg_ptr[i + 1]; ++g) F.cg2[2 * i + (g - F.cg_ptr[i])] = F.cg_slot[g];
+        bool four = true;
+        for (int64_t i = 0; i < foff && four; ++i) four = (F.cg_ptr[i + 1] - F.cg_ptr[i]) <= 4;
+        F.cg4.clear();
+        if (four) {
+            F.cg4.assign(4 * (size_t)foff, -1);
+            for (int64_t i = 0; i < foff; ++i) for (int64_t g = F.cg_ptr[i]; g < F.cg_ptr[i + 1]; ++g) F.cg4[4 * i + (g - F.cg_ptr[i])] = F.cg_slot[g];
         }
     }
     F.panels.clear();

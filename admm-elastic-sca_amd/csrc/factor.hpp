@@ -45,7 +45,7 @@ struct Factor {
     std::vector<std::vector<int>> levels;  // supernodes per level (level 0 = leaves)
     std::vector<int64_t> cg_ptr;           // per front row (front_off[s] + i): range into cg_slot
     std::vector<int> cg_slot;              // the CHILDREN's contribution slots that land on that front row (child order)
-    std::vector<int> cg2;                  // [front rows][2]: the same lists when no row has more than 2 entries (-1 = none), else empty
+    std::vector<int> cg4;                  // [front rows][4]: the same lists when no row has more than 4 entries (-1 = none), else empty
     int64_t n_slots = 0;                   // sum of nrows
     int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
     int max_cols = 0, max_rows = 0;
@@ -57,7 +57,9 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 
 // Geometric nested dissection on the graph of A using node coordinates
 // xyz[n][3]; fills perm/iperm, supernodes, rows, levels, gather lists.
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F);
+// merge_above > 0: regions with more nodes than that become four-way tree nodes (their separator and the two half-separators
+// in one supernode): half as many elimination-tree levels for a little more fill.
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0);
 
 // Multifrontal numeric factorization; fills F.panels.  Returns 0 or a
 // non-zero code when A is not positive definite.

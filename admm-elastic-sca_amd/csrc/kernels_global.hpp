@@ -233,7 +233,7 @@ struct FactorDev {
     const int *rows;
     const int64_t *cg_ptr;   // per front row: children's contribution slots landing on it
     const int *cg_slot;
-    const int2 *cg2;         // same lists as fixed pairs (binary elimination trees), or NULL
+    const int4 *cg4;         // same lists as fixed quadruples (-1 = none; trees with <= 4 contributions per front row), or NULL
 };
 
 // One work item of a sweep launch with everything the block needs to start, in one 64-byte record
@@ -252,9 +252,11 @@ template <bool CG2>
 __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const double *__restrict__ C, double &s0, double &s1, double &s2) {
     s0 = 0.0; s1 = 0.0; s2 = 0.0;
     if (CG2) {
-        const int2 ab = F.cg2[fr];
+        const int4 ab = F.cg4[fr];
         if (ab.x >= 0) { const double *c = C + 3 * (size_t)ab.x; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
         if (ab.y >= 0) { const double *c = C + 3 * (size_t)ab.y; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+        if (ab.z >= 0) { const double *c = C + 3 * (size_t)ab.z; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+        if (ab.w >= 0) { const double *c = C + 3 * (size_t)ab.w; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
     } else {
         for (int64_t g = F.cg_ptr[fr]; g < F.cg_ptr[fr + 1]; ++g) {
             const double *c = C + 3 * (size_t)F.cg_slot[g];
@@ -360,9 +362,11 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__
         const int row = tile * 64 + ln;
         if (row < f && row >= k) {
             if (CG2) {
-                const int2 ab = F.cg2[foff + row];
+                const int4 ab = F.cg4[foff + row];
                 if (ab.x >= 0) carry += C[3 * (size_t)ab.x + c];
                 if (ab.y >= 0) carry += C[3 * (size_t)ab.y + c];
+                if (ab.z >= 0) carry += C[3 * (size_t)ab.z + c];
+                if (ab.w >= 0) carry += C[3 * (size_t)ab.w + c];
             } else {
                 for (int64_t g = F.cg_ptr[foff + row]; g < F.cg_ptr[foff + row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c];
             }
