@@ -56,7 +56,7 @@ template <int W, int D, int THREADS> void run(const char *name, const double *P,
 int main() {
     const size_t total = (size_t)96 << 20;   // doubles: 768 MB
     double *P, *out; hipMalloc(&P, total * 8); hipMalloc(&out, 1 << 20); hipMemset(P, 0, total * 8);
-    struct { int F, K, panels; } cfg[] = {{2560, 704, 8}, {2560, 704, 32}, {1408, 320, 32}, {1408, 320, 128}, {1024, 1024, 1}, {2176, 1088, 2}};
+    struct { int F, K, panels; } cfg[] = {{128, 64, 2068}, {128, 64, 8272}, {2560, 704, 8}, {2560, 704, 32}, {1408, 320, 32}, {1408, 320, 128}, {1024, 1024, 1}, {2176, 1088, 2}};
     for (auto c : cfg) {
         if ((size_t)c.F * c.K * c.panels > total) continue;
         run<8, 8, 1024>("8B/lane D=8 1024thr", P, c.F, c.K, c.panels, out);
