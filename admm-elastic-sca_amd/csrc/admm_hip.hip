@@ -923,6 +923,15 @@ int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
     for (int i = 0; i < ctx->n_nodes; ++i) owner[i] = (ctx->shard_mode == ADMM_SHARD_SUBTREE && ctx->world > 1) ? ctx->node_owner[ctx->F.iperm[i]] : 0;
     return ADMM_OK;
 }
+#ifdef ADMM_TET_PROFILE
+// tools/tet_phase_profile.py only (variant build): read and clear the tet kernel's phase counters
+extern "C" int admm_hip_debug_tet_profile(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 32) != hipSuccess) return ADMM_ERR_HIP;
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_tet_prof), zero, sizeof(zero)) != hipSuccess) return ADMM_ERR_HIP;
+    return ADMM_OK;
+}
+#endif
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->allreduce = fn; ctx->allreduce_user = user;

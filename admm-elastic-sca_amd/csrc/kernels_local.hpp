@@ -152,8 +152,10 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
     if (e >= n) return;
     double B[12];
     Mat3 Dx, u, F, z;
+    ADMM_PROF_T0
     tet_load(b, x, e, n, B, Dx, u);
     F = mat_add(Dx, u);
+    ADMM_PROF_TIME(0);
     if (KIND <= 1) {
 #if ADMM_LOCAL_NT >= 2
         const double mu = ld_stream(&b.par[(size_t)0 * n + e]), lambda = ld_stream(&b.par[(size_t)1 * n + e]);
@@ -181,6 +183,7 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
         z.m01 = (k * p.m01 + w2 * F.m01) / den; z.m11 = (k * p.m11 + w2 * F.m11) / den; z.m21 = (k * p.m21 + w2 * F.m21) / den;
         z.m02 = (k * p.m02 + w2 * F.m02) / den; z.m12 = (k * p.m12 + w2 * F.m12) / den; z.m22 = (k * p.m22 + w2 * F.m22) / den;
     }
+    ADMM_PROF_TIME(4);      // the whole projection incl. parameter / state traffic (1 + 2 + 3 are inside it)
     // (Measured and dropped: re-deriving B, Dx, u from memory here instead of keeping them live
     // across the projection saves ~20 VGPRs but not enough for a third wave per SIMD: -2 %.)
     // u += Dx - z ; q = z - u
@@ -203,6 +206,10 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
     o1[0] = f[3]; o1[1] = f[4]; o1[2] = f[5];
     o2[0] = f[6]; o2[1] = f[7]; o2[2] = f[8];
     o3[0] = f[9]; o3[1] = f[10]; o3[2] = f[11];
+    ADMM_PROF_TIME(5);
+#if ADMM_PROF_ON
+    if (threadIdx.x == 0) atomicAdd(&admm_dev::g_tet_prof[16], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------

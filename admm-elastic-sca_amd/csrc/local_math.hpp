@@ -16,6 +16,8 @@
 #include <float.h>
 #include <math.h>
 
+#include "log_glibc_data.hpp"
+
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define ADMM_HD __host__ __device__ __forceinline__
 #else
@@ -30,6 +32,34 @@
 #endif
 
 namespace admm_dev {
+
+// ---- phase attribution of the tet kernel (tools/tet_phase_profile.py; build flag -DADMM_TET_PROFILE, never on in the
+// shipped library): s_memtime deltas accumulated by lane 0 of every wave, per-lane loop counts as (sum, 64 x wave maximum)
+#if defined(ADMM_TET_PROFILE) && defined(__HIPCC__)
+__device__ unsigned long long g_tet_prof[32];
+#endif
+#if defined(ADMM_TET_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ void prof_time(int idx, unsigned long long &t) {
+    const unsigned long long n = prof_now();
+    if (threadIdx.x == 0) atomicAdd(&g_tet_prof[idx], n - t);
+    t = prof_now();
+}
+__device__ __forceinline__ void prof_count(int idx, int v) {
+    int sum = v, mx = v;
+    for (int o = 32; o; o >>= 1) { sum += __shfl_xor(sum, o); const int other = __shfl_xor(mx, o); mx = other > mx ? other : mx; }
+    if (threadIdx.x == 0) { atomicAdd(&g_tet_prof[idx], (unsigned long long)sum); atomicAdd(&g_tet_prof[idx + 1], (unsigned long long)(64 * mx)); }
+}
+#define ADMM_PROF_T0 unsigned long long prof_t = admm_dev::prof_now();
+#define ADMM_PROF_TIME(i) admm_dev::prof_time(i, prof_t)
+#define ADMM_PROF_COUNT(i, v) admm_dev::prof_count(i, v)
+#define ADMM_PROF_ON 1
+#else
+#define ADMM_PROF_T0
+#define ADMM_PROF_TIME(i)
+#define ADMM_PROF_COUNT(i, v)
+#define ADMM_PROF_ON 0
+#endif
 
 // libstdc++ std::min / std::max (second argument wins only on strict compare;
 // this fixes what happens with NaNs exactly like the reference build)
@@ -157,12 +187,19 @@ ADMM_HD void svd3(const Mat3 &F, Mat3 &U, double &s0, double &s1, double &s2, Ma
     W.m02 = F.m02 / scale; W.m12 = F.m12 / scale; W.m22 = F.m22 / scale;
     U = identity3(); V = identity3();
     bool finished = false;
+#if ADMM_PROF_ON
+    int prof_sweeps = 0, prof_rot = 0;
+#endif
     while (!finished) {
         bool a = jacobi_pq<1, 0>(W, U, V);
         bool b = jacobi_pq<2, 0>(W, U, V);
         bool c = jacobi_pq<2, 1>(W, U, V);
         finished = !(a || b || c);
+#if ADMM_PROF_ON
+        prof_sweeps++; prof_rot += (int)a + (int)b + (int)c;
+#endif
     }
+    ADMM_PROF_COUNT(8, prof_sweeps); ADMM_PROF_COUNT(10, prof_rot);
     double a0 = fabs(W.m00), a1 = fabs(W.m11), a2 = fabs(W.m22);
     if (a0 != 0.0) scale_col<0>(U, unit_sign(W.m00));
     if (a1 != 0.0) scale_col<1>(U, unit_sign(W.m11));
@@ -208,10 +245,77 @@ struct V3 { double a, b, c; };
 ADMM_HD double dotd(const V3 &x, const V3 &y) { return (x.a * y.a + x.b * y.b) + x.c * y.c; } // dynamic-size order
 ADMM_HD double absmax(const V3 &x) { double r = fabs(x.a); r = smax(r, fabs(x.b)); r = smax(r, fabs(x.c)); return r; }
 
+// ---- log(): glibc's double-precision algorithm, restated ----------------------------------------------------------------
+// NHProx calls libm's log() (CORE/TetForce.cpp:229-262).  OCML's log differs from it in the last bit on ~10 % of the
+// arguments, which the reference's L-BFGS then amplifies; so the device evaluates glibc's own algorithm (glibc >= 2.28
+// sysdeps/ieee754/dbl-64/e_log.c: z = x / 2^k in [0x1.6p-1, 0x1.6p0), 128-entry table of (1/c, log c), r = z/c - 1,
+// degree-5 polynomial; a degree-11 polynomial in r = x - 1 for 1 - 2^-4 <= x < 1 + 0x1.09p-4) with glibc's constants
+// (log_glibc_data.hpp) in the operation order of the build x86-64 hosts with FMA run (ifunc variant __log_fma: the
+// fused operations below are the ones GCC contracted there, read off its object code; every other a*b+c stays two
+// roundings).  tests/test_host_math.py::test_log: bit-identical with libm over 4M arguments incl. all special cases.
+// About half the instructions of OCML's log.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double g_log_tab[256] = ADMM_LOG_TAB;
+#else
+static const double g_log_tab[256] = ADMM_LOG_TAB;
+#endif
+ADMM_HD unsigned long long dbl_bits(double x) { unsigned long long u; __builtin_memcpy(&u, &x, 8); return u; }
+ADMM_HD double bits_dbl(unsigned long long u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+ADMM_HD double admm_log(double x) {
+    const double A[5] = ADMM_LOG_A, B[11] = ADMM_LOG_B;
+    unsigned long long ix = dbl_bits(x);
+    double res;
+    if (ix - 0x3fee000000000000ull < 0x0003090000000000ull) {       // 1 - 0x1p-4 <= x < 1 + 0x1.09p-4
+        const double r = x - 1.0;
+        const double r2 = r * r, r3 = r * r2;
+        const double p1 = __builtin_fma(r2, B[3], __builtin_fma(r, B[2], B[1]));
+        const double p4 = __builtin_fma(r2, B[6], __builtin_fma(r, B[5], B[4]));
+        double p7 = __builtin_fma(r2, B[9], __builtin_fma(r, B[8], B[7]));
+        p7 = __builtin_fma(r3, B[10], p7);
+        const double pol = __builtin_fma(__builtin_fma(p7, r3, p4), r3, p1);
+        const double t = __builtin_fma(r, 0x1p27, r);              // r + w, w = r * 2^27
+        const double rhi = __builtin_fma(-0x1p27, r, t);            // (r + w) - w
+        const double rlo = r - rhi;
+        const double rh2 = rhi * rhi;
+        const double hi = __builtin_fma(rh2, B[0], r);
+        double lo = __builtin_fma(rh2, B[0], r - hi);
+        lo = __builtin_fma(B[0] * rlo, r + rhi, lo);
+        res = hi + __builtin_fma(pol, r3, lo);
+        if (ix == 0x3ff0000000000000ull) res = 0.0;
+    } else {
+        const unsigned top = (unsigned)(ix >> 48);
+        const bool special = top - 0x0010u >= 0x7ff0u - 0x0010u;      // zero, subnormal, negative, inf, nan
+        if (special) ix = dbl_bits(x * 0x1p52) - (52ull << 52);       // (subnormal: renormalise; the others are overridden below)
+        const unsigned long long tmp = ix - 0x3fe6000000000000ull;
+        const int i = (int)((tmp >> 45) & 127);
+        const int k = (int)((long long)tmp >> 52);
+        const double z = bits_dbl(ix - (tmp & 0xfff0000000000000ull));
+        const double invc = g_log_tab[2 * i], logc = g_log_tab[2 * i + 1];
+        const double kd = (double)k;
+        const double r = __builtin_fma(z, invc, -1.0);
+        const double w = __builtin_fma(kd, ADMM_LOG_LN2HI, logc);
+        const double hi = w + r;
+        const double lo = __builtin_fma(kd, ADMM_LOG_LN2LO, (w - hi) + r);
+        const double r2 = r * r;
+        const double q = __builtin_fma(__builtin_fma(r, A[4], A[3]), r2, __builtin_fma(r, A[2], A[1]));
+        res = __builtin_fma(r * r2, q, __builtin_fma(r2, A[0], lo)) + hi;
+        if (special) {
+            const unsigned long long ax = dbl_bits(x);
+            if (ax * 2 == 0) res = -__builtin_inf();
+            else if (ax == 0x7ff0000000000000ull) res = x;
+            else if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) res = __builtin_nan("");
+        }
+    }
+    return res;
+}
+
 // ---- prox objective: NHProx / StVKProx, CORE/TetForce.cpp:216-297 ----------
 template <int TYPE> struct Prox {
     double mu, lambda, k;
     V3 s0;
+#if ADMM_PROF_ON
+    mutable int prof_nfev = 0;
+#endif
 
     ADMM_HD double value(const V3 &x) const {
         if (x.a < 0.0 || x.b < 0.0 || x.c < 0.0) return kFltMax;
@@ -220,7 +324,7 @@ template <int TYPE> struct Prox {
             double Sig_det = (x.a * x.b * x.c);
             double I_1 = x.a * x.a + x.b * x.b + x.c * x.c;
             double I_3 = Sig_det * Sig_det;
-            double log_I3 = log(I_3);
+            double log_I3 = admm_log(I_3);
             double t1 = 0.5 * mu * (I_1 - log_I3 - 3.0);
             double t2 = 0.125 * lambda * log_I3 * log_I3;
             double r = t1 + t2;
@@ -242,7 +346,7 @@ template <int TYPE> struct Prox {
             double detSigma = x.a * x.b * x.c;
             if (detSigma <= 0.0) { g.a = g.b = g.c = 1.0 * kFltMax; return g; }
             double ia = 1.0 / x.a, ib = 1.0 / x.b, ic = 1.0 / x.c;
-            double ll = lambda * log(detSigma);
+            double ll = lambda * admm_log(detSigma);
             g.a = 1.0 * (mu * (x.a - ia) + ll * ia) + k * (x.a - s0.a);
             g.b = 1.0 * (mu * (x.b - ib) + ll * ib) + k * (x.b - s0.b);
             g.c = 1.0 * (mu * (x.c - ic) + ll * ic) + k * (x.c - s0.c);
@@ -258,69 +362,62 @@ template <int TYPE> struct Prox {
 };
 
 // ---- MoreThuente::cstep, OPT/linesearch/morethuente.h:169-308 ---------------
+// The reference's four cases (fp > fx | sgnd < 0 | |dp| < |dx| | else) each evaluate the same cubic-step expression tree on
+// different operands.  The lanes of a wavefront sit in different cases (and would execute all four bodies one after the
+// other: 24 divisions + 4 square roots per call), so the operands are selected first and the tree is evaluated ONCE
+// (7 divisions + 1 square root).  Every lane still performs exactly its own case's operations on its own case's operands
+// in the reference's order, so the results are bitwise those of the branching form (tests/test_host_math.py runs this
+// code on the host against the reference's cstep through the projection fixtures).
 ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
                       double fp, double dp, bool &brackt, double stpmin, double stpmax, int &info) {
     info = 0;
-    bool bound = false;
     if ((brackt & ((stp <= smin(stx, sty)) | (stp >= smax(stx, sty)))) | (dx * (stp - stx) >= 0.0) | (stpmax < stpmin)) return;
-    double sgnd = dp * unit_sign(dx);
-    double stpf = 0, stpc = 0, stpq = 0;
-    if (fp > fx) {
-        info = 1; bound = true;
-        double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
-        double s = smax(theta, smax(dx, dp));
-        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp < stx) gamma = -gamma;
-        double p = (gamma - dx) + theta;
-        double q = ((gamma - dx) + gamma) + dp;
-        double r = p / q;
-        stpc = stx + r * (stp - stx);
-        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.) * (stp - stx);
+    const double sgnd = dp * unit_sign(dx);
+    const bool c1 = fp > fx;
+    const bool c2 = !c1 & (sgnd < 0.0);
+    const bool c3 = !c1 & !c2 & (fabs(dp) < fabs(dx));
+    const bool c4 = !c1 & !c2 & !c3;
+    info = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : 4));
+    const bool bound = c1 | c3;
+#ifdef ADMM_CSTEP_STATS     // tests/host_math_shim.cpp: which cases the fixtures reach
+    ADMM_CSTEP_STATS[info + (brackt ? 4 : 0)]++;
+#endif
+    // theta = 3 (f_a - f_b) / (st_b - st_a) + d_a + dp        (:187, :216, :245, :283)
+    const double num = c4 ? fp - fy : fx - fp;
+    const double den = c4 ? sty - stp : stp - stx;
+    const double d1 = c4 ? dy : dx;
+    const double theta = 3. * num / den + d1 + dp;
+    const double s = smax(theta, smax(d1, dp));
+    double rad = (theta / s) * (theta / s) - (d1 / s) * (dp / s);
+    if (c3) rad = smax(0., rad);
+    double gamma = s * sqrt(rad);
+    const bool flip = c1 ? (stp < stx) : (c4 ? (stp > sty) : (stp > stx));
+    if (flip) gamma = -gamma;
+    const double gp = gamma - (c1 ? dx : dp);
+    const double p = gp + theta;
+    const double q = c3 ? ((gamma + (dx - dp)) + gamma) : ((gp + gamma) + (c1 ? dp : (c2 ? dx : dy)));
+    const double r = p / q;
+    double stpc = (c1 ? stx : stp) + r * (c1 ? stp - stx : (c4 ? sty - stp : stx - stp));
+    if (c3 & !((r < 0.0) & (gamma != 0.0))) stpc = (stp > stx) ? stpmax : stpmin;
+    // quadratic / secant step: case 1 :196, cases 2 and 3 :224, :263
+    const double qd = c1 ? ((fx - fp) / (stp - stx) + dx) : (dp - dx);
+    const double ratio = (c1 ? dx : dp) / qd;
+    const double stpq = c1 ? stx + (ratio / 2.) * (stp - stx) : stp + ratio * (stx - stp);
+    double stpf;
+    if (c1) {
         if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
         else stpf = stpc + (stpq - stpc) / 2;
         brackt = true;
-    } else if (sgnd < 0.0) {
-        info = 2; bound = false;
-        double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        double s = smax(theta, smax(dx, dp));
-        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
-        if (stp > stx) gamma = -gamma;
-        double p = (gamma - dp) + theta;
-        double q = ((gamma - dp) + gamma) + dx;
-        double r = p / q;
-        stpc = stp + r * (stx - stp);
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    } else if (c2) {
         if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
         else stpf = stpq;
         brackt = true;
-    } else if (fabs(dp) < fabs(dx)) {
-        info = 3; bound = true;
-        double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        double s = smax(theta, smax(dx, dp));
-        double gamma = s * sqrt(smax(0., (theta / s) * (theta / s) - (dx / s) * (dp / s)));
-        if (stp > stx) gamma = -gamma;
-        double p = (gamma - dp) + theta;
-        double q = (gamma + (dx - dp)) + gamma;
-        double r = p / q;
-        if ((r < 0.0) & (gamma != 0.0)) stpc = stp + r * (stx - stp);
-        else if (stp > stx) stpc = stpmax;
-        else stpc = stpmin;
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    } else if (c3) {
         if (brackt) { if (fabs(stp - stpc) < fabs(stp - stpq)) stpf = stpc; else stpf = stpq; }
         else { if (fabs(stp - stpc) > fabs(stp - stpq)) stpf = stpc; else stpf = stpq; }
     } else {
-        info = 4; bound = false;
-        if (brackt) {
-            double theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
-            double s = smax(theta, smax(dy, dp));
-            double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
-            if (stp > sty) gamma = -gamma;
-            double p = (gamma - dp) + theta;
-            double q = ((gamma - dp) + gamma) + dy;
-            double r = p / q;
-            stpc = stp + r * (sty - stp);
-            stpf = stpc;
-        } else if (stp > stx) stpf = stpmax;
+        if (brackt) stpf = stpc;
+        else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
     if (fp > fx) { sty = stp; fy = fp; dy = dp; }
@@ -370,6 +467,9 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         g = prob.gradient(xn);
         g_out = g; evaluated = true;
         nfev++;
+#if ADMM_PROF_ON
+        prob.prof_nfev++;
+#endif
         double dg = dotd(g, s);
         double ftest1 = finit + stp * dgtest;
         if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
@@ -380,21 +480,27 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         if ((f <= ftest1) & (fabs(dg) <= gtol * (-dginit))) info = 1;
         if (info != 0) return stp;
         if (stage1 & (f <= ftest1) & (dg >= smin(ftol, gtol) * dginit)) stage1 = false;
-        if (stage1 & (f <= fx) & (f > ftest1)) {
-            double fm = f - stp * dgtest;
-            double fxm = fx - stx * dgtest;
-            double fym = fy - sty * dgtest;
-            double dgm = dg - dgtest;
-            double dgxm = dgx - dgtest;
-            double dgym = dgy - dgtest;
-            mt_cstep(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, brackt, stmin, stmax, infoc);
-            fx = fxm + stx * dgtest;
-            fy = fym + sty * dgtest;
-            dgx = dgxm + dgtest;
-            dgy = dgym + dgtest;
-        } else {
-            mt_cstep(stx, fx, dgx, sty, fy, dgy, stp, f, dg, brackt, stmin, stmax, infoc);
+        // modified function in stage 1 (:118-138): one cstep call on selected operands (see mt_cstep)
+        const bool modified = stage1 & (f <= fx) & (f > ftest1);
+        double cf = f, cdg = dg, cfx = fx, cfy = fy, cdgx = dgx, cdgy = dgy;
+        if (modified) {
+#ifdef ADMM_CSTEP_STATS
+            ADMM_CSTEP_STATS[0]++;
+#endif
+            cf = f - stp * dgtest;
+            cfx = fx - stx * dgtest;
+            cfy = fy - sty * dgtest;
+            cdg = dg - dgtest;
+            cdgx = dgx - dgtest;
+            cdgy = dgy - dgtest;
         }
+        mt_cstep(stx, cfx, cdgx, sty, cfy, cdgy, stp, cf, cdg, brackt, stmin, stmax, infoc);
+        if (modified) {
+            fx = cfx + stx * dgtest;
+            fy = cfy + sty * dgtest;
+            dgx = cdgx + dgtest;
+            dgy = cdgy + dgtest;
+        } else { fx = cfx; fy = cfy; dgx = cdgx; dgy = cdgy; }
         if (brackt) {
             if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
             width1 = width;
@@ -554,7 +660,9 @@ template <int M, class P> ADMM_HD int lbfgs_minimize_reg(const P &prob, V3 &x0, 
 template <int TYPE, int M>
 ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter, double &sa, double &sb, double &sc, double &hess, int &n_iters) {
     double s0, s1, s2; Mat3 U, V;
+    ADMM_PROF_T0
     oriented_svd(F, s0, s1, s2, U, V);
+    ADMM_PROF_TIME(1);
     Prox<TYPE> P;
     P.mu = mu; P.lambda = lambda; P.k = smin(mu, lambda);
     P.s0.a = s0; P.s0.b = s1; P.s0.c = s2;
@@ -567,7 +675,15 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
 #endif
     sa = x2.a; sb = x2.b; sc = x2.c;
+    ADMM_PROF_TIME(2);
+#if ADMM_PROF_ON
+    ADMM_PROF_COUNT(12, n_iters); ADMM_PROF_COUNT(14, P.prof_nfev);
+    const Mat3 zr = recompose(U, x2.a, x2.b, x2.c, V);
+    ADMM_PROF_TIME(3);
+    return zr;
+#else
     return recompose(U, x2.a, x2.b, x2.c, V);
+#endif
 }
 
 // ---- LinearTetStrain::project (CORE/TetForce.cpp:127-153) and TetVolume::project (:173-210)
@@ -757,6 +873,9 @@ ADMM_HD void project_triarea_p(const double d[6], int iters, double lmin, double
 // (every reduction in the L-BFGS / line search is (a + b) + c, so the zero third component leaves
 // the arithmetic of the 2-variable solver untouched)
 struct FungProx {
+#if ADMM_PROF_ON
+    mutable int prof_nfev = 0;
+#endif
     double mu, k;
     V3 s0;
     ADMM_HD double value(const V3 &x) const {

@@ -3,11 +3,16 @@
 // test-suite can compare it against the oracle without a GPU.  This library is
 // never loaded by the product; the product path runs the same header inside
 // the HIP kernels only.
+static long g_cstep_stats[9];   // [0] modified-function calls, [case] / [4 + case]: cstep case reached without / with a bracket
+#define ADMM_CSTEP_STATS g_cstep_stats
 #include "../admm-elastic-sca_amd/csrc/local_math.hpp"
 using namespace admm_dev;
 static Mat3 ld(const double *f) { Mat3 m; m.m00=f[0]; m.m10=f[1]; m.m20=f[2]; m.m01=f[3]; m.m11=f[4]; m.m21=f[5]; m.m02=f[6]; m.m12=f[7]; m.m22=f[8]; return m; }
 static void st(const Mat3 &m, double *f) { f[0]=m.m00; f[1]=m.m10; f[2]=m.m20; f[3]=m.m01; f[4]=m.m11; f[5]=m.m21; f[6]=m.m02; f[7]=m.m12; f[8]=m.m22; }
 extern "C" {
+void hm_cstep_stats(long *out) { for (int i = 0; i < 9; ++i) out[i] = g_cstep_stats[i]; }
+void hm_libm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = log(x[i]); }   // this host's libm: what the reference calls
+void hm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = admm_log(x[i]); }
 void hm_svd3(const double *F, double *U, double *S, double *V) {
     Mat3 u, v; svd3(ld(F), u, S[0], S[1], S[2], v); st(u, U); st(v, V);
 }

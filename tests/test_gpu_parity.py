@@ -4,15 +4,14 @@ with the committed golden vectors from the compiled reference, and -- at the
 benchmark's full size -- through size-independent properties.
 
 Tolerances
-  * local step of every kind without log(): BIT-EXACT vs the oracle
-    (StVK, corotational tet, tet volume, bend, spring, anchors);
-  * Neo-Hookean local step: the only difference is OCML log() vs glibc log()
-    (<= 1 ulp).  Where that last bit does not flip a branch of the truncated
-    L-BFGS / More-Thuente search the result agrees to 1e-9 relative; elements
-    where it does (different line-search path) are counted and must stay < 3 %,
-    and even those stay within 0.1 of |z| (they are different but equally valid
-    truncated minimisations -- the reference shows the same spread under a
-    1-ulp perturbation of its own input);
+  * local step of every kind but two: BIT-EXACT vs the oracle and vs the
+    reference's recorded project() tuples (Neo-Hookean -- the device evaluates
+    glibc's log() algorithm, local_math.hpp admm_log --, StVK, corotational tet,
+    tet volume, triangle area, bend, spring, anchors, collisions);
+  * FungTriangle: the objective calls exp() (OCML vs glibc, <= 1 ulp).  Where that
+    last bit does not flip a branch of the truncated L-BFGS / More-Thuente search
+    the result agrees to 1e-9 relative; elements where it does are counted and
+    must stay < 3 %, and even those stay within 0.1 of |z|;
   * triangle strain: polar factor by closed form instead of Jacobi SVD: 1e-12;
   * solve: residual <= 1e-11 relative; vs the oracle's LDL^T 1e-10;
   * one ADMM iteration (no chaos yet): 1e-11;  multi-frame trajectories:
@@ -76,7 +75,8 @@ def oracle_local_step(o, xcur, n, rows):
     return u.copy().reshape(n, rows), z.copy().reshape(n, rows)
 
 
-EXACT_CASES = [("TET_STVK", [100.0, 100.0, 5]), ("TET_STVK", [3e3, 1e3, 9]), ("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]),
+EXACT_CASES = [("TET_NH", [1e5, 1e5, 5]), ("TET_NH", [100.0, 150.0, 5]), ("TET_NH", [50.0, 80.0, 12]),
+               ("TET_STVK", [100.0, 100.0, 5]), ("TET_STVK", [3e3, 1e3, 9]), ("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]),
                ("BEND", [20.0]), ("SPRING", [50.0]), ("ANCHOR", [-1.0, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_AREA", [30.0, 1, 1.0, 1.0])]
 
 
@@ -95,9 +95,9 @@ def test_local_step_bit_exact(pkg, name, params):
         u, z = oracle_local_step(o, xcur, n, rows)
         assert np.array_equal(g["z"], z, equal_nan=True), (name, it)
         assert np.array_equal(g["u"], u, equal_nan=True), (name, it)
-        if name.startswith("TET_STVK"):
+        if name in ("TET_STVK", "TET_NH"):
             st = np.array([o.hyper_state(i)[0] for i in range(n)]); ni = np.array([o.hyper_state(i)[1] for i in range(n)])
-            assert np.array_equal(g["state"], st) and np.array_equal(g["n_iters"], ni)
+            assert np.array_equal(g["state"], st, equal_nan=True) and np.array_equal(g["n_iters"], ni)
 
 
 @pytest.mark.parametrize("params", [[1e5, 1e5, 5], [100.0, 150.0, 5], [50.0, 80.0, 12]])
@@ -117,13 +117,13 @@ def test_local_step_neohookean(pkg, params):
         same = ni == g["n_iters"]
         sc = np.maximum(1.0, np.abs(z).max(axis=1))
         err = np.abs(g["z"] - z).max(axis=1) / sc
-        good = err < 1e-9
+        good = err == 0.0
         differ += int((~good).sum()); total += n
-        assert np.isfinite(g["z"]).all() and err.max() < 0.1
+        assert np.isfinite(g["z"]).all() and same.all()
         # re-synchronise the device with the oracle so the next iteration starts from identical state
         st = np.array([o.hyper_state(i)[0] for i in range(n)])
         s.write_local(0, u=u, state=st)
-    assert differ <= 0.03 * total, (differ, total)
+    assert differ == 0, (differ, total)      # admm_log() is glibc's log: the whole prox is bit-identical
 
 
 def test_local_step_triangle(pkg):
@@ -183,7 +183,7 @@ def test_golden_project_tuples(pkg, name):
     if name.startswith("TET"):
         assert np.array_equal(rest["rest"], g["init"][:, 1:13])       # B, bit-exact
     s.write_local(0, u=g["u0"])
-    exact = name not in ("TET_NH", "TRI_STRAIN", "TRI_FUNG")
+    exact = name not in ("TRI_STRAIN", "TRI_FUNG")
     bad = 0
     for c in range(g["Dx"].shape[1]):
         s.local_step_dx(0, g["Dx"][:, c])
@@ -191,7 +191,7 @@ def test_golden_project_tuples(pkg, name):
         if exact:
             assert np.array_equal(out["z"], g["z"][:, c], equal_nan=True), (name, c)
             assert np.array_equal(out["u"], g["u"][:, c], equal_nan=True), (name, c)
-            if name == "TET_STVK":
+            if name in ("TET_STVK", "TET_NH"):
                 assert np.array_equal(out["n_iters"], g["n_iters"][:, c])
         else:
             fin = np.isfinite(g["z"][:, c]).all(axis=1) & np.isfinite(g["u"][:, c]).all(axis=1)   # a few Fung tuples overflow in the reference
@@ -205,8 +205,8 @@ def test_golden_project_tuples(pkg, name):
                 s.write_local(0, u=g["u"][:, c])
             else:
                 assert err.max() < 1e-12
-    if exact and name == "TET_STVK":
-        assert np.array_equal(s.read_local(0)["state"], g["state"])
+    if exact and name in ("TET_STVK", "TET_NH"):
+        assert np.array_equal(s.read_local(0)["state"], g["state"], equal_nan=True)
     assert bad <= 0.03 * N * g["Dx"].shape[1]
 
 

@@ -19,6 +19,8 @@ def hm():
     out = os.path.join(HERE, "_build", "libhostmath.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, os.path.join(HERE, "host_math_shim.cpp")])
     lib = C.CDLL(out)
+    lib.hm_log.argtypes = [C.c_int, dp, dp]
+    lib.hm_libm_log.argtypes = [C.c_int, dp, dp]
     lib.hm_project_hyper.argtypes = [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_int, dp, dp]
     lib.hm_project_tet_p.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
     lib.hm_project_triarea_p.argtypes = [dp, C.c_int, C.c_double, C.c_double, dp]
@@ -28,6 +30,28 @@ def hm():
 
 def _p(a):
     return a.ctypes.data_as(dp)
+
+
+def test_log(hm):
+    """admm_log (glibc's algorithm restated for the device) against this host's libm log(): every bit, 4M arguments --
+    the range the prox uses (det sigma, (det sigma)^2 around 1), all binades, subnormals, the special cases."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.uniform(0.5, 2.0, 1_000_000), 1.0 + rng.normal(size=1_000_000) * 10.0 ** rng.uniform(-12, -0.5, 1_000_000),
+        np.exp(rng.uniform(-700, 700, 1_000_000)), rng.uniform(0.93, 1.07, 900_000),
+        np.frombuffer(rng.integers(0, 2 ** 63, 100_000, dtype=np.int64).tobytes(), np.float64),      # any positive bit pattern
+        np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, -1.0, 5e-324, 2.2250738585072014e-308, 1e-310, 1.7976931348623157e308,
+                  1 - 2.0 ** -4, np.nextafter(1 - 2.0 ** -4, 0), 1 + float.fromhex("0x1.09p-4"), np.nextafter(1 + float.fromhex("0x1.09p-4"), 0),
+                  np.nextafter(1.0, 2), np.nextafter(1.0, 0), float.fromhex("0x1.6p-1"), float.fromhex("0x1.6p0")])])
+    y = np.zeros_like(x); ref = np.zeros_like(x)
+    hm.hm_log(C.c_int(x.size), _p(x), _p(y))
+    hm.hm_libm_log(C.c_int(x.size), _p(x), _p(ref))
+    ok = ~np.isnan(ref)
+    assert ok.sum() > x.size - 100_000
+    bad = np.nonzero(y.view(np.int64)[ok] != ref.view(np.int64)[ok])[0]
+    assert bad.size == 0, (bad.size, x[ok][bad[:5]])
+    assert np.all(np.isnan(y[~ok]))
+    assert y[-19] == -np.inf and y[-18] == -np.inf and y[-17] == 0.0 and y[-16] == np.inf      # log(+-0), log(1), log(inf)
 
 
 def test_svd3(hm):
@@ -69,6 +93,20 @@ def test_project_hyper(hm, name, params, M):
             u = u + (Dx[c] - z)
             assert np.array_equal(z, b["z"][c], equal_nan=True) and it == b["n_iters"][c] and np.array_equal(u, b["u"][c], equal_nan=True)
         assert np.array_equal(st, b["state"], equal_nan=True)
+
+
+def test_linesearch_case_coverage(hm):
+    """The More-Thuente step selection is written as one expression tree on selected operands (local_math.hpp mt_cstep);
+    the bit-exact projections above only pin it if they reach every case, with and without a bracket, and the stage-1
+    modified function."""
+    test_project_hyper(hm, "TET_NH", [50, 80, 20], 10)
+    test_project_hyper(hm, "TET_STVK", [3e3, 1e3, 12], 10)
+    st = (C.c_long * 9)()
+    hm.hm_cstep_stats(st)
+    st = list(st)
+    assert st[0] > 0, st                                   # modified function
+    assert all(st[c] > 0 for c in (1, 2, 3, 4)), st        # cases 1-4 before a bracket exists
+    assert all(st[4 + c] > 0 for c in (1, 2, 3, 4)), st    # and with one
 
 
 def test_project_tet_blend(hm):

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Phase attribution of project_tet_kernel (GPU box): builds a variant of
+libadmm_hip.so with -DADMM_TET_PROFILE (s_memtime stamps at the phase boundaries,
+per-lane loop counts reduced per wave), runs the bar, prints where a wave's
+lifetime goes and how much of each loop is lost to lanes waiting for the slowest
+lane of their wave.
+
+  python tools/tet_phase_profile.py [dims=32x32x163] [frames=3]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = r'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, %r)
+from __graft_entry__ import load_package
+pkg = load_package()
+s = pkg.make_bar_system(*%r, device_id=0)
+s.initialize()
+lib = pkg.lib()
+buf = (ctypes.c_ulonglong * 32)()
+frames = %d
+for f in range(frames):
+    s.step(20)
+    s.m_x
+    assert lib.admm_hip_debug_tet_profile(buf) == 0
+    v = np.array(buf[:], dtype=np.float64)
+    waves = v[16]
+    names = ["load (idx, x gather, rest, u)", "oriented_svd", "L-BFGS prox", "recompose", "projection total (1+2+3+par/state)", "epilogue (u, z, RHS slots)"]
+    tot = v[0] + v[4] + v[5]
+    print("frame %%d: %%d wave-launches, mean wave lifetime %%.0f ticks" %% (f, waves, tot / waves))
+    for i, nm in enumerate(names):
+        print("   %%-40s %%6.1f %%%%" %% (nm, 100 * v[i] / tot))
+    for nm, i in (("Jacobi sweeps", 8), ("Jacobi rotations", 10), ("L-BFGS outer iterations", 12), ("line-search evaluations", 14)):
+        print("   %%-28s mean per tet %%6.2f   mean of wave maxima %%6.2f   -> lane efficiency %%.2f" %% (nm, v[i] / (64 * waves), v[i + 1] / (64 * waves), v[i] / max(v[i + 1], 1)))
+'''
+
+
+def main():
+    dims, frames = (32, 32, 163), 3
+    for a in sys.argv[1:]:
+        if a.startswith("dims="):
+            dims = tuple(int(v) for v in a[5:].split("x"))
+        if a.startswith("frames="):
+            frames = int(a[7:])
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    out = os.path.join(ROOT, "admm-elastic-sca_amd", "_build", "libadmm_hip_prof.so")
+    pkg._build.build(force=False, extra_hip_flags=["-DADMM_TET_PROFILE"], out=out, tag="_prof")
+    env = dict(os.environ, ADMM_HIP_LIB=out)
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, dims, frames)], env=env, capture_output=True, text=True)
+    print(r.stdout)
+    if r.returncode:
+        print(r.stderr[-2000:])
+
+
+if __name__ == "__main__":
+    main()
