@@ -309,6 +309,61 @@ ADMM_HD double admm_log(double x) {
     return res;
 }
 
+// ---- exp(): glibc's algorithm, same treatment (FungProx, CORE/TriangleForce.cpp:171-223, calls libm's exp) --------------
+// glibc sysdeps/ieee754/dbl-64/e_exp.c: k/N = round(x N / ln 2), r = x - k ln2/N, 2^(k/N) from a 128-entry table, degree-5
+// polynomial; results near the over/underflow thresholds go through its specialcase() scaling.  Operation order of the
+// x86-64 FMA build (__exp_fma).  tests/test_host_math.py::test_exp: bit-identical with libm, all ranges.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const unsigned long long g_exp_tab[256] = ADMM_EXP_TAB;
+#else
+static const unsigned long long g_exp_tab[256] = ADMM_EXP_TAB;
+#endif
+ADMM_HD double admm_exp(double x) {
+    const double C[4] = ADMM_EXP_C;
+    const unsigned long long ix = dbl_bits(x);
+    unsigned abstop = (unsigned)(ix >> 52) & 0x7ffu;
+    if (abstop - 0x3c9u > 0x3eu) {                                   // |x| < 2^-54 or |x| >= 512 or not finite
+        if ((int)(abstop - 0x3c9u) < 0) return 1.0 + x;
+        if (abstop > 0x408u) {                                       // |x| >= 1024, inf, nan
+            if (ix == 0xfff0000000000000ull) return 0.0;
+            if (abstop == 0x7ffu) return 1.0 + x;
+            return (ix >> 63) ? 0.0 : __builtin_inf();               // (__math_uflow / __math_oflow)
+        }
+        abstop = 0;                                                  // 512 <= |x| < 1024: the result may need the careful scaling
+    }
+    double kd = __builtin_fma(x, ADMM_EXP_INVLN2N, ADMM_EXP_SHIFT);
+    const unsigned long long ki = dbl_bits(kd);
+    kd = kd - ADMM_EXP_SHIFT;
+    const double r = __builtin_fma(kd, ADMM_EXP_NEGLN2LON, __builtin_fma(kd, ADMM_EXP_NEGLN2HIN, x));
+    const int idx = 2 * (int)(ki & 127);
+    const double tail = bits_dbl(g_exp_tab[idx]);
+    unsigned long long sbits = g_exp_tab[idx + 1] + (ki << 45);
+    const double r2 = r * r;
+    const double lowp = __builtin_fma(__builtin_fma(r, C[1], C[0]), r2, r + tail);
+    const double tmp = __builtin_fma(r2 * r2, __builtin_fma(r, C[3], C[2]), lowp);
+    if (abstop == 0) {                                               // e_exp.c specialcase()
+        if ((ki & 0x80000000ull) == 0) {                             // k > 0: scale by 2^-1009 first, the product may overflow
+            sbits -= 1009ull << 52;
+            const double scale = bits_dbl(sbits);
+            return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+        }
+        sbits += 1022ull << 52;                                      // k < 0: the result may be subnormal
+        const double scale = bits_dbl(sbits);
+        const double st = tmp * scale;
+        double y = scale + st;
+        if (y < 1.0) {
+            double lo = (scale - y) + st;
+            const double hi = 1.0 + y;
+            lo = ((1.0 - hi) + y) + lo;
+            y = (lo + hi) - 1.0;
+            if (y == 0.0) y = 0.0;
+        }
+        return 0x1p-1022 * y;
+    }
+    const double scale = bits_dbl(sbits);
+    return __builtin_fma(scale, tmp, scale);
+}
+
 // ---- prox objective: NHProx / StVKProx, CORE/TetForce.cpp:216-297 ----------
 template <int TYPE> struct Prox {
     double mu, lambda, k;
@@ -884,7 +939,7 @@ struct FungProx {
         const double s3 = 1.0 / (x.a * x.b);
         const double I_1 = x.a * x.a + x.b * x.b + s3 * s3;
         const double t1 = mu / (b * 2.0);
-        const double t2 = exp(b * (I_1 - 3.0)) - 1.0;
+        const double t2 = admm_exp(b * (I_1 - 3.0)) - 1.0;
         const double r0 = isfinite(t2) ? (t1 * t2) : kFltMax;
         const double da = x.a - s0.a, db = x.b - s0.b;
         const double r2 = (k * 0.5) * (da * da + db * db);
@@ -897,7 +952,7 @@ struct FungProx {
         const double b = 1.0;
         const double sig3 = 1.0 / (x.a * x.b);
         const double I_1 = (x.a * x.a + x.b * x.b + sig3 * sig3);
-        const double t1 = 0.5 * mu * exp(b * (I_1 - 3.0));
+        const double t1 = 0.5 * mu * admm_exp(b * (I_1 - 3.0));
         const double t20 = k * (x.a - s0.a), t21 = k * (x.b - s0.b);
         g.a = t1 * (2.0 * x.a - 2.0 / (x.a * x.a * x.a * x.b * x.b)) + t20;
         g.b = t1 * (2.0 * x.b - 2.0 / (x.b * x.b * x.b * x.a * x.a)) + t21;

@@ -12,6 +12,8 @@ static void st(const Mat3 &m, double *f) { f[0]=m.m00; f[1]=m.m10; f[2]=m.m20; f
 extern "C" {
 void hm_cstep_stats(long *out) { for (int i = 0; i < 9; ++i) out[i] = g_cstep_stats[i]; }
 void hm_libm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = log(x[i]); }   // this host's libm: what the reference calls
+void hm_libm_exp(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = exp(x[i]); }
+void hm_exp(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = admm_exp(x[i]); }
 void hm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = admm_log(x[i]); }
 void hm_svd3(const double *F, double *U, double *S, double *V) {
     Mat3 u, v; svd3(ld(F), u, S[0], S[1], S[2], v); st(u, U); st(v, V);

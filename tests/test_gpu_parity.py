@@ -7,11 +7,8 @@ Tolerances
   * local step of every kind but two: BIT-EXACT vs the oracle and vs the
     reference's recorded project() tuples (Neo-Hookean -- the device evaluates
     glibc's log() algorithm, local_math.hpp admm_log --, StVK, corotational tet,
-    tet volume, triangle area, bend, spring, anchors, collisions);
-  * FungTriangle: the objective calls exp() (OCML vs glibc, <= 1 ulp).  Where that
-    last bit does not flip a branch of the truncated L-BFGS / More-Thuente search
-    the result agrees to 1e-9 relative; elements where it does are counted and
-    must stay < 3 %, and even those stay within 0.1 of |z|;
+    tet volume, triangle area, FungTriangle -- glibc's exp(), admm_exp --, bend,
+    spring, anchors, collisions);
   * triangle strain: polar factor by closed form instead of Jacobi SVD: 1e-12;
   * solve: residual <= 1e-11 relative; vs the oracle's LDL^T 1e-10;
   * one ADMM iteration (no chaos yet): 1e-11;  multi-frame trajectories:
@@ -77,7 +74,8 @@ def oracle_local_step(o, xcur, n, rows):
 
 EXACT_CASES = [("TET_NH", [1e5, 1e5, 5]), ("TET_NH", [100.0, 150.0, 5]), ("TET_NH", [50.0, 80.0, 12]),
                ("TET_STVK", [100.0, 100.0, 5]), ("TET_STVK", [3e3, 1e3, 9]), ("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]),
-               ("BEND", [20.0]), ("SPRING", [50.0]), ("ANCHOR", [-1.0, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_AREA", [30.0, 1, 1.0, 1.0])]
+               ("BEND", [20.0]), ("SPRING", [50.0]), ("ANCHOR", [-1.0, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_AREA", [30.0, 1, 1.0, 1.0]),
+               ("TRI_FUNG", [50.0, 0.5, 2.0]), ("TRI_FUNG", [5.0, 0.5, 2.0])]
 
 
 @pytest.mark.parametrize("name,params", EXACT_CASES)
@@ -140,8 +138,8 @@ def test_local_step_triangle(pkg):
 
 
 def test_local_step_fung(pkg):
-    """FungTriangle: bit-exact 3x2 Jacobi SVD, then an L-BFGS whose objective calls exp() (OCML vs glibc):
-    like Neo-Hookean, nearly all elements agree to rounding, a few take a different line-search branch."""
+    """FungTriangle: bit-exact 3x2 Jacobi SVD, then an L-BFGS whose objective calls exp() -- glibc's algorithm on the
+    device (admm_exp): every finite element bit-identical; the tuples the reference itself drives to NaN are skipped."""
     n = 1200
     s, o, X, idx, rng = build_disjoint(pkg, "TRI_FUNG", [50.0, 0.5, 2.0], n, seed=8)
     differ = 0; total = 0
@@ -153,8 +151,8 @@ def test_local_step_fung(pkg):
         fin = np.isfinite(z).all(axis=1) & np.isfinite(u).all(axis=1)
         sc = np.maximum(1.0, np.abs(z[fin]).max(axis=1))
         err = np.abs(g["z"][fin] - z[fin]).max(axis=1) / sc
-        differ += int((~(err < 1e-9)).sum()) + int((~fin).sum()); total += n
-        assert np.isfinite(g["z"][fin]).all() and err.max() < 0.1
+        differ += int((~(err == 0.0)).sum()); total += n
+        assert np.isfinite(g["z"][fin]).all()
         st = np.array([o.hyper_state(i)[0] for i in range(n)])
         u[~fin] = 0.0; st[~np.isfinite(st)] = 1.0
         s.write_local(0, u=u, state=st)
@@ -183,7 +181,7 @@ def test_golden_project_tuples(pkg, name):
     if name.startswith("TET"):
         assert np.array_equal(rest["rest"], g["init"][:, 1:13])       # B, bit-exact
     s.write_local(0, u=g["u0"])
-    exact = name not in ("TRI_STRAIN", "TRI_FUNG")
+    exact = name != "TRI_STRAIN"
     bad = 0
     for c in range(g["Dx"].shape[1]):
         s.local_step_dx(0, g["Dx"][:, c])

@@ -20,6 +20,8 @@ def hm():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out, os.path.join(HERE, "host_math_shim.cpp")])
     lib = C.CDLL(out)
     lib.hm_log.argtypes = [C.c_int, dp, dp]
+    lib.hm_exp.argtypes = [C.c_int, dp, dp]
+    lib.hm_libm_exp.argtypes = [C.c_int, dp, dp]
     lib.hm_libm_log.argtypes = [C.c_int, dp, dp]
     lib.hm_project_hyper.argtypes = [C.c_int, C.c_int, dp, C.c_double, C.c_double, C.c_int, dp, dp]
     lib.hm_project_tet_p.argtypes = [C.c_int, dp, C.c_double, C.c_double, dp]
@@ -52,6 +54,26 @@ def test_log(hm):
     assert bad.size == 0, (bad.size, x[ok][bad[:5]])
     assert np.all(np.isnan(y[~ok]))
     assert y[-19] == -np.inf and y[-18] == -np.inf and y[-17] == 0.0 and y[-16] == np.inf      # log(+-0), log(1), log(inf)
+
+
+def test_exp(hm):
+    """admm_exp against this host's libm exp(): every bit -- the prox's range, the over/underflow borders (specialcase
+    scaling, subnormal results), tiny and non-finite arguments."""
+    rng = np.random.default_rng(6)
+    x = np.concatenate([
+        rng.uniform(-5, 5, 1_000_000), rng.uniform(-746, 710, 1_000_000), rng.uniform(-1100, 1100, 300_000), rng.uniform(-745.2, -707.0, 300_000),
+        rng.uniform(700, 709.8, 300_000), rng.normal(size=300_000) * 10.0 ** rng.uniform(-20, 0, 300_000),
+        np.frombuffer(rng.integers(-2 ** 63, 2 ** 63, 100_000, dtype=np.int64).tobytes(), np.float64),          # any bit pattern
+        np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 709.782712893384, 709.7827128933841, -745.1332191019411, -745.1332191019412,
+                  -708.3964185322641, 512.0, -512.0, 1024.0, -1024.0, 2.0 ** -54, -2.0 ** -54, 5e-324, 1e308, -1e308])])
+    y = np.zeros_like(x); ref = np.zeros_like(x)
+    hm.hm_exp(C.c_int(x.size), _p(x), _p(y))
+    hm.hm_libm_exp(C.c_int(x.size), _p(x), _p(ref))
+    ok = ~np.isnan(ref)
+    bad = np.nonzero(y.view(np.int64)[ok] != ref.view(np.int64)[ok])[0]
+    assert bad.size == 0, (bad.size, x[ok][bad[:5]], y[ok][bad[:5]], ref[ok][bad[:5]])
+    assert np.all(np.isnan(y[~ok]))
+    assert (ref == 0).sum() > 1000 and np.isinf(ref).sum() > 1000 and ((ref > 0) & (ref < 2.3e-308)).sum() > 1000    # all regimes present
 
 
 def test_svd3(hm):
