@@ -392,23 +392,14 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
     double zi[6];
     const double s = b.w2h2[e];
     if (MODE == 0) {
-        // C = F^T F (2x2), polar factor T = F C^{-1/2}
-        const double c00 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-        const double c01 = d[0] * d[3] + d[1] * d[4] + d[2] * d[5];
-        const double c11 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
-        const double detC = c00 * c11 - c01 * c01;
-        double T[6];
-        {
-            // sqrt of SPD 2x2: S = (C + sqrt(det) I) / sqrt(tr + 2 sqrt(det)); T = F S^-1
-            const double sd = sqrt(detC > 0.0 ? detC : 0.0);
-            const double tr = c00 + c11;
-            const double den = sqrt(tr + 2.0 * sd);
-            const double s00 = (c00 + sd) / den, s01 = c01 / den, s11 = (c11 + sd) / den;
-            const double ds = s00 * s11 - s01 * s01;
-            const double i00 = s11 / ds, i01 = -s01 / ds, i11 = s00 / ds;
+        // T = U(:, :2) V^T from the reference's own 3x2 Jacobi SVD (TriangleForce.cpp:83-92): bit-identical with it.
+        // (The closed form F (F^T F)^-1/2 is 4x cheaper and agrees to 1e-12, but this kernel is bandwidth-bound anyway.)
+        double U2[6], V[4], sv0, sv1, T[6];
+        svd32(d, U2, sv0, sv1, V);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { T[j] = d[j] * i00 + d[3 + j] * i01; T[3 + j] = d[j] * i01 + d[3 + j] * i11; }
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T[i + 3 * j] = U2[i] * V[j] + U2[i + 3] * V[j + 2];
         const double k = b.kblend[e], w2 = b.w2[e];
 #pragma unroll
         for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
