@@ -4,8 +4,8 @@
 //
 // Built with -ffp-contract=off: the operation order below is the order the
 // reference's Eigen/cppoptlib expressions evaluate in on x86-64 SSE2 (no FMA),
-// so every kernel that does not call log() is bit-identical to the reference;
-// the Neo-Hookean prox differs only through OCML's log() vs glibc's (<= 1 ulp).
+// and log() / exp() are glibc's algorithms (admm_log, admm_exp below), so every
+// local step -- the Neo-Hookean and Fung proxes included -- is bit-identical to the reference.
 //
 // Reference (under /root/reference):
 //   CORE = deps/admm-elastic-sca/src/system
@@ -246,7 +246,7 @@ ADMM_HD double dotd(const V3 &x, const V3 &y) { return (x.a * y.a + x.b * y.b) +
 ADMM_HD double absmax(const V3 &x) { double r = fabs(x.a); r = smax(r, fabs(x.b)); r = smax(r, fabs(x.c)); return r; }
 
 // ---- log(): glibc's double-precision algorithm, restated ----------------------------------------------------------------
-// NHProx calls libm's log() (CORE/TetForce.cpp:229-262).  OCML's log differs from it in the last bit on ~10 % of the
+// NHProx calls libm's log() (CORE/TetForce.cpp:229-262).  OCML's log differs from it in the last bit on part of the
 // arguments, which the reference's L-BFGS then amplifies; so the device evaluates glibc's own algorithm (glibc >= 2.28
 // sysdeps/ieee754/dbl-64/e_log.c: z = x / 2^k in [0x1.6p-1, 0x1.6p0), 128-entry table of (1/c, log c), r = z/c - 1,
 // degree-5 polynomial; a degree-11 polynomial in r = x - 1 for 1 - 2^-4 <= x < 1 + 0x1.09p-4) with glibc's constants
