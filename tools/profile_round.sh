@@ -16,7 +16,11 @@ rm -rf /tmp/prof_stats
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/bench_1M_kernel_stats.csv
 head -12 gpurun_out/bench_1M_kernel_stats.csv | cut -c1-160
 # 4. per-level picture of one ADMM iteration + the mixed scene
-python tools/level_trace.py /tmp/prof_stats > gpurun_out/level_trace_1M.txt 2>&1
+ADMM_HIP_VERBOSE=1 python tools/run_steps.py 32 32 163 1 2>&1 | grep "admm_hip: level" > gpurun_out/level_trace_1M.txt
+python tools/level_trace.py /tmp/prof_stats >> gpurun_out/level_trace_1M.txt 2>&1
 tail -12 gpurun_out/level_trace_1M.txt
 python bench.py --config mixed > gpurun_out/bench_mixed.json 2>/dev/null
 tail -1 gpurun_out/bench_mixed.json | cut -c1-200
+# 5. where a tet-kernel wave spends its life (instrumented variant build)
+python tools/tet_phase_profile.py frames=2 > gpurun_out/tet_phase_profile.txt 2>&1
+tail -11 gpurun_out/tet_phase_profile.txt
