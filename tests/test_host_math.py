@@ -34,6 +34,23 @@ def _p(a):
     return a.ctypes.data_as(dp)
 
 
+def test_glibc_constants_match_this_libm(tmp_path):
+    """csrc/log_glibc_data.hpp is generated from libm.so.6 (tools/extract_log_table.py): regenerating it from this image's
+    libm must reproduce the committed header byte for byte."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("extract_log_table", os.path.join(HERE, "..", "tools", "extract_log_table.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = tmp_path / "log_glibc_data.hpp"
+    argv = list(__import__("sys").argv)
+    try:
+        __import__("sys").argv = ["extract_log_table.py"]
+        mod.main(str(out))
+    finally:
+        __import__("sys").argv = argv
+    committed = open(os.path.join(HERE, "..", "admm-elastic-sca_amd", "csrc", "log_glibc_data.hpp")).read()
+    assert out.read_text() == committed
+
+
 def test_log(hm):
     """admm_log (glibc's algorithm restated for the device) against this host's libm log(): every bit, 4M arguments --
     the range the prox uses (det sigma, (det sigma)^2 around 1), all binades, subnormals, the special cases."""
