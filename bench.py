@@ -104,6 +104,8 @@ def main():
     if os.environ.get("ADMM_BENCH_SHARE_GPU"):
         local_rank = 0
     backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
+    if torch.cuda.device_count() <= local_rank:     # launcher that pins one visible device per rank
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
