@@ -93,6 +93,7 @@ struct admm_hip_ctx {
     // device state (node arrays in factor order)
     double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
     double *d_fslot = nullptr; int64_t n_fslots = 0;
+    int slot_stride = 0;                      // > 0: RHS slots rank-major (slot of a node's r-th incidence = r * slot_stride + node), 0: node-sorted
     int64_t *d_inc_ptr = nullptr;
     double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr, *d_cg4 = nullptr;
     int64_t *d_sn_panel_off = nullptr, *d_sn_rows_off = nullptr, *d_sn_slot_off = nullptr, *d_sn_front_off = nullptr, *d_cg_ptr = nullptr;
@@ -476,8 +477,15 @@ int upload_all(admm_hip_ctx *ctx) {
         }
         slot += (int64_t)b.n_local * nn; nloc += b.n_local;
     }
-    for (int i = 0; i < n; ++i) inc_ptr[i + 1] += inc_ptr[i];
+    int64_t maxdeg = 0;
+    for (int i = 0; i < n; ++i) { maxdeg = std::max(maxdeg, inc_ptr[i + 1]); inc_ptr[i + 1] += inc_ptr[i]; }
     std::vector<int64_t> inc_pos(inc_ptr.begin(), inc_ptr.end() - 1);
+    // RHS slot layout.  Node-sorted (a node's incidences contiguous) makes the gather's lanes -- one per (node, component) --
+    // read 24-byte pieces 0.5 KB apart; rank-major (all nodes' r-th incidence contiguous) makes neighbouring lanes read
+    // neighbouring words for every r, and neighbouring tets of a wave write neighbouring slots.  Same summation order per node
+    // (r ascending = batch, element, corner), so the results are bitwise the same.  It pads every node to the largest incidence
+    // count: used unless that more than doubles the array (meshes with a few very high-valence nodes).
+    ctx->slot_stride = (maxdeg * n <= 2 * inc_ptr[n] + 1024 && getenv("ADMM_HIP_SLOTS_NODE_SORTED") == nullptr) ? n : 0;
     // pass 2: device arrays; every corner gets the next slot of its node (fixed order: batch, element, corner)
     for (Batch &b : ctx->batches) {
         const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
@@ -492,7 +500,8 @@ int upload_all(admm_hip_ctx *ctx) {
             for (int c = 0; c < nn; ++c) {
                 const int pn = F.iperm[id[ord[c]]];
                 idx[(size_t)el * ist + c] = pn;
-                dst[(size_t)el * ist + c] = (int)inc_pos[pn]++;
+                const int64_t r = inc_pos[pn]++;
+                dst[(size_t)el * ist + c] = ctx->slot_stride ? (int)((r - inc_ptr[pn]) * ctx->slot_stride + pn) : (int)r;
             }
             const double *R = &b.rest[(size_t)e * 12];
             if (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) {
@@ -528,7 +537,10 @@ int upload_all(admm_hip_ctx *ctx) {
             TRY(upload(ctx, &b.d_targets, tg)); TRY(upload(ctx, &b.d_active, ac));
         }
     }
-    ctx->n_fslots = slot; ctx->info.n_elems_local = nloc;
+    ctx->info.n_elems_local = nloc;
+    if (ctx->slot_stride) slot = maxdeg * n;
+    if (slot >= (int64_t)1 << 31) return fail(ctx, ADMM_ERR_UNSUPPORTED, "more than 2^31 RHS slots");
+    ctx->n_fslots = slot;
     TRY(dalloc(ctx, &ctx->d_fslot, 3 * (size_t)std::max<int64_t>(slot, 1)));
     HIPCHK(hipMemset(ctx->d_fslot, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slot, 1)));
     TRY(upload(ctx, &ctx->d_inc_ptr, inc_ptr));
@@ -618,7 +630,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
 
 int launch_rhs(admm_hip_ctx *ctx) {
     const int n3 = 3 * ctx->n_nodes;
-    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr,
+    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride,
                        ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, (const unsigned char *)ctx->d_base_mask, ctx->d_y);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
@@ -702,6 +714,7 @@ int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
             TRY(upload(ctx, &b.d_G, b.G));
             slots += (int64_t)b.n_local * ADMM_KIND_NODES[b.kind]; maxn = std::max(maxn, b.n_local);
         }
+        slots = std::max<int64_t>(slots, ctx->n_fslots);      // same layout as the RHS slots
         TRY(dalloc(ctx, &ctx->d_res_slots, 3 * (size_t)std::max<int64_t>(slots, 1)));
         HIPCHK(hipMemset(ctx->d_res_slots, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slots, 1)));
         TRY(dalloc(ctx, &ctx->d_res_s, 3 * (size_t)ctx->n_nodes));
@@ -742,7 +755,7 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
         first = false;
     }
     if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
+    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
     if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
         if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
         if (ctx->allreduce(ctx->allreduce_user, ctx->d_res_s, (int64_t)n3, (void *)ctx->stream) != 0 || ctx->allreduce(ctx->allreduce_user, r2, 1, (void *)ctx->stream) != 0)

@@ -107,11 +107,10 @@ __global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, dou
 
 // One lane per dof: b = base + sum of the node's incident per-corner
 // contributions.  The local kernels write every corner's 24 bytes straight to
-// its position in the node's incidence list (node-sorted slots), so this is a
-// contiguous streaming read in fixed (batch, element, corner) order.
+// its slot (layouts: admm_hip.hip upload_all), summed here in fixed (batch, element, corner) order.
 // base = M x_bar exactly once across ranks: on rank 0 (contiguous sharding: add_base), or where base_mask says this
 // rank is responsible for the node (subtree sharding: the owner of the node's subtree; rank 0 for the replicated top).
-__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr,
+__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr, int slot_stride,
                                   const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base,
                                   const unsigned char *__restrict__ base_mask, double *__restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,7 +118,13 @@ __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_p
     const int node = i / 3, c = i - 3 * node;
     double acc = 0.0;
     const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
-    for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
+    if (slot_stride) {      // rank-major slots: lane i reads word i of every rank's array
+        const int deg = (int)(p1 - p0);
+        const double *f = fslot + i;
+        for (int r = 0; r < deg; ++r) acc += f[3 * (size_t)r * slot_stride];
+    } else {
+        for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
+    }
     const bool base = base_mask ? (base_mask[node] != 0) : (add_base != 0);
     y[i] = base ? (mxbar[i] + acc) : acc;
 }
