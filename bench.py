@@ -239,6 +239,13 @@ def main():
                    "x_checksum": float(np.abs(xs).sum())},
         "roofline": roof,
     }
+    if world > 1:      # per-rank phase times (ms per ADMM iteration) and element counts: where the scaling goes
+        keys = ["local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms", "total_ms"]
+        mine = torch.tensor([phase[k] / iters_total for k in keys] + [float(info["n_elems_local"])], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        out["per_rank"] = {k: [round(float(t[i]), 4) for t in allr] for i, k in enumerate(keys)}
+        out["per_rank"]["elements"] = [int(t[len(keys)]) for t in allr]
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 side figure
             try:

@@ -311,5 +311,7 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0 and "cpu_baseline" not in two
     assert two["config"]["parallelism"].startswith("x2: elements and elimination subtrees")
+    pr = two["per_rank"]                                       # per-rank phase times and element counts travel with the line
+    assert len(pr["local_ms"]) == 2 and min(pr["total_ms"]) > 0 and sum(pr["elements"]) == 8 * 8 * 40 * 6 + 9 * 9
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
