@@ -39,7 +39,12 @@ def build_oracle():
 
 
 def have_ref():
-    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libadmm_ref.so"))
+    """The compiled reference (oracle/_ref, built from /root/reference where that exists -- this container; the GPU box
+    only has what was built here).  Built on first use so that the suite does not depend on __graft_entry__.build() having run."""
+    lib = os.path.join(ORACLE_DIR, "_ref", "libadmm_ref.so")
+    if not os.path.exists(lib) and os.path.isdir("/root/reference"):
+        subprocess.call(["make", "-s", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.exists(lib)
 
 
 class _Sys:
