@@ -117,6 +117,7 @@ def lib():
         L.admm_hip_local_step_dx.argtypes = [C.c_void_p, C.c_int, _dp]
         L.admm_hip_apply_A.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_panel_solve_host.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp]
         L.admm_hip_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.admm_hip_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
@@ -351,6 +352,13 @@ class System:
         x = np.ascontiguousarray(x, dtype=np.float64).ravel()
         y = np.zeros_like(x)
         self._chk(self.L.admm_hip_apply_A(self.h, _d(x), _d(y)))
+        return y
+
+    def debug_math(self, op, x):
+        """the device's log (op 0) / exp (op 1) on an array (parity tests)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._chk(self.L.admm_hip_debug_math(self.h, int(op), x.size, _d(x), _d(y)))
         return y
 
     def debug_panel_solve_host(self, b):

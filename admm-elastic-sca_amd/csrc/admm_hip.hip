@@ -1259,6 +1259,30 @@ int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *
     return ADMM_OK;
 }
 
+namespace admm_dev {
+__global__ void debug_math_kernel(int op, int64_t n, const double *__restrict__ in, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = op == 0 ? admm_log(in[i]) : admm_exp(in[i]);
+}
+} // namespace admm_dev
+int admm_hip_debug_math(admm_hip_ctx *ctx, int op, int64_t n, const double *in, double *out) {
+    TRY(require_device(ctx));
+    if (!in || !out || n < 0 || op < 0 || op > 1) return ADMM_ERR_ARG;
+    if (n == 0) return ADMM_OK;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_in, sizeof(double) * n)); 
+    if (hipMalloc(&d_out, sizeof(double) * n) != hipSuccess) { (void)hipFree(d_in); return fail(ctx, ADMM_ERR_HIP, "hipMalloc failed"); }
+    int rc = ADMM_OK;
+    if (hipMemcpy(d_in, in, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) rc = ADMM_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(admm_dev::debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, n, (const double *)d_in, d_out);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = ADMM_ERR_HIP;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc ? fail(ctx, rc, "debug_math failed") : ADMM_OK;
+}
+
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info) {
     if (!ctx || !info) return ADMM_ERR_ARG;
     *info = ctx->info;

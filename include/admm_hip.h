@@ -180,6 +180,10 @@ int admm_hip_apply_A(admm_hip_ctx *ctx, const double *x, double *y);
  * CPU test-suite only; no product path calls it.                               */
 int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *x);
 
+/* the device's log() / exp() (glibc's algorithms restated, local_math.hpp admm_log / admm_exp) applied to n doubles:
+ * op 0 = log, 1 = exp.  Parity tests compare them bit for bit with the host's libm.                                */
+int admm_hip_debug_math(admm_hip_ctx *ctx, int op, int64_t n, const double *in, double *out);
+
 typedef struct admm_hip_info {
     int64_t n_nodes, n_elems_total, n_elems_local, rows_compact;
     int64_t nnz_A;            /* scalar n x n system, lower triangle          */

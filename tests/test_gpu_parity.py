@@ -18,6 +18,7 @@ import pytest
 
 from checkers import KIND, KIND_NODES, KIND_ROWS, Oracle
 from conftest import golden
+from test_host_math import hm  # noqa: F401  (fixture: the host build of local_math.hpp + this host's libm)
 from test_oracle_golden import tol
 
 pytestmark = pytest.mark.gpu
@@ -636,3 +637,29 @@ def test_mixed_scene(pkg):
     for _ in range(3):
         s.step(20)
     assert np.isfinite(s.m_x).all()
+
+
+def test_device_log_exp_bitwise(pkg, hm):
+    """admm_log / admm_exp as the GPU executes them (fused multiply-adds, table loads, subnormal handling on the device)
+    against this host's libm, 2M arguments each: every bit.  (tests/test_host_math.py checks the same header on the CPU.)"""
+    import ctypes as C
+    s = pkg.make_bar_system(2, 2, 3)
+    s.initialize()
+    rng = np.random.default_rng(17)
+    specials = np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, -1.0, 5e-324, 2.2250738585072014e-308, 1e-310, 1.7976931348623157e308,
+                         1 - 2.0 ** -4, 1 + float.fromhex("0x1.09p-4"), 709.782712893384, -745.1332191019411, -708.3964185322641, 512.0, -512.0, 1024.0, -1024.0])
+    xl = np.concatenate([rng.uniform(0.5, 2.0, 500_000), 1.0 + rng.normal(size=500_000) * 10.0 ** rng.uniform(-12, -0.5, 500_000),
+                         np.exp(rng.uniform(-740, 709, 500_000)), rng.uniform(0.93, 1.07, 400_000),
+                         np.frombuffer(rng.integers(0, 2 ** 63, 100_000, dtype=np.int64).tobytes(), np.float64), specials])
+    xe = np.concatenate([rng.uniform(-5, 5, 500_000), rng.uniform(-746, 710, 500_000), rng.uniform(-1100, 1100, 300_000), rng.uniform(-745.2, -707.0, 300_000),
+                         rng.uniform(700, 709.8, 200_000), rng.normal(size=100_000) * 10.0 ** rng.uniform(-20, 0, 100_000),
+                         np.frombuffer(rng.integers(-2 ** 63, 2 ** 63, 100_000, dtype=np.int64).tobytes(), np.float64), specials])
+    for op, x, ref_fn in ((0, xl, hm.hm_libm_log), (1, xe, hm.hm_libm_exp)):
+        x = np.ascontiguousarray(x)
+        ref = np.zeros_like(x)
+        ref_fn(C.c_int(x.size), x.ctypes.data_as(C.POINTER(C.c_double)), ref.ctypes.data_as(C.POINTER(C.c_double)))
+        got = s.debug_math(op, x)
+        ok = ~np.isnan(ref)
+        bad = np.nonzero(got.view(np.int64)[ok] != ref.view(np.int64)[ok])[0]
+        assert bad.size == 0, (op, bad.size, x[ok][bad[:5]], got[ok][bad[:5]], ref[ok][bad[:5]])
+        assert np.all(np.isnan(got[~ok]))
