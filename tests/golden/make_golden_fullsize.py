@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Full-size fixture from the COMPILED REFERENCE (oracle/_ref, run in this container only; ~1 h of CPU: its
+`initialize` alone is 23 min at this size): the benchmark's 1,001,472-tet Neo-Hookean bar (BASELINE.json configs[3],
+32x32x163 cubes), ONE frame of 20 ADMM iterations from rest under gravity.
+
+  traj_bar_1M.npz   x after the frame at every 8th node (+ sums over all nodes), the same from a start perturbed by
+                    1 ulp (a second reference instance): the reference's own sensitivity = the resolution at which
+                    anything can be compared with it at this size.
+
+  python tests/golden/make_golden_fullsize.py        (writes tests/golden/traj_bar_1M.npz)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import KIND, Ref, bar_system  # noqa: E402
+
+DIMS = (32, 32, 163)
+STRIDE = 8
+
+
+def run(perturb):
+    t0 = time.time()
+    r = bar_system(Ref, KIND["TET_NH"], DIMS, 1e5, 1e5, 20, perturb=perturb)
+    t1 = time.time()
+    r.step()
+    t2 = time.time()
+    x = r.x.copy().reshape(-1, 3)
+    print("perturb %g: initialize %.0f s, one frame (20 iterations) %.0f s" % (perturb, t1 - t0, t2 - t1), flush=True)
+    del r
+    return x, t1 - t0, t2 - t1
+
+
+def main():
+    xa, t_init, t_step = run(0.0)
+    np.savez_compressed(os.path.join(HERE, "traj_bar_1M_partial.npz"), x=xa[::STRIDE])          # keep something if the second run dies
+    xb, _, _ = run(2e-16)
+    sens = float(np.abs(xa - xb).max())
+    np.savez_compressed(os.path.join(HERE, "traj_bar_1M.npz"), dims=np.array(DIMS), stride=STRIDE, iters=20, dt=0.04, mu=1e5, lam=1e5, max_iter=5,
+                        x_sample=xa[::STRIDE], sum_abs=float(np.abs(xa).sum()), sum_sq=float((xa * xa).sum()), n_nodes=xa.shape[0],
+                        ulp_sensitivity=sens, ulp_sensitivity_sample=float(np.abs(xa[::STRIDE] - xb[::STRIDE]).max()),
+                        ref_initialize_s=t_init, ref_frame_s=t_step)
+    os.remove(os.path.join(HERE, "traj_bar_1M_partial.npz"))
+    print("1-ulp sensitivity after one frame: %.3e (max |x| %.3f)" % (sens, np.abs(xa).max()))
+
+
+if __name__ == "__main__":
+    main()

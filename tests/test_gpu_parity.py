@@ -507,6 +507,28 @@ def test_full_size_properties(pkg):
     assert np.array_equal(xa, xb)
 
 
+def test_full_size_bar_vs_compiled_reference(pkg):
+    """The benchmark workload itself against the COMPILED REFERENCE: tests/golden/traj_bar_1M.npz holds the reference's
+    positions (every 8th node + sums over all nodes) after one frame = 20 ADMM iterations of the 1,001,472-tet Neo-Hookean
+    bar, and its own sensitivity to a 1-ulp perturbation of the start (make_golden_fullsize.py: about an hour of reference
+    CPU time, of which 23 min are its initialize).  The local steps are bit-identical, the solves differ by rounding; the
+    bound is 20 x the reference's sensitivity like for every other trajectory fixture."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_bar_1M.npz")):
+        pytest.skip("full-size fixture not generated")
+    g = golden("traj_bar_1M.npz")
+    s = pkg.make_bar_system(*[int(v) for v in g["dims"]])
+    s.initialize()
+    assert s.n_nodes == int(g["n_nodes"])
+    s.step(int(g["iters"]))
+    x = s.m_x.reshape(-1, 3)
+    bound = max(1e-9, 20.0 * float(g["ulp_sensitivity"]))
+    err = np.abs(x[::int(g["stride"])] - g["x_sample"]).max()
+    assert err < bound, (err, bound)
+    assert abs(np.abs(x).sum() - float(g["sum_abs"])) < bound * x.size
+    assert abs((x * x).sum() - float(g["sum_sq"])) < bound * x.size
+
+
 def test_full_size_mixed_scene_properties(pkg):
     """BASELINE.json configs[4] at full size (498,888 NH+StVK tets, 99,856 triangles, 149k hinges, anchors; two
     disconnected bodies in one factorization): every force kernel in one step -- size-independent properties."""
