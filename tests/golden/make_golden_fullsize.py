@@ -7,7 +7,10 @@
                     1 ulp (a second reference instance): the reference's own sensitivity = the resolution at which
                     anything can be compared with it at this size.
 
-  python tests/golden/make_golden_fullsize.py        (writes tests/golden/traj_bar_1M.npz)
+  traj_mixed_full.npz   the same for BASELINE.json configs[4] at full size (498,888 NH + StVK tets, 99,856 triangles, 149k hinges).
+
+  python tests/golden/make_golden_fullsize.py          (writes tests/golden/traj_bar_1M.npz)
+  python tests/golden/make_golden_fullsize.py mixed    (writes tests/golden/traj_mixed_full.npz)
 """
 import os
 import sys
@@ -35,7 +38,43 @@ def run(perturb):
     return x, t1 - t0, t2 - t1
 
 
+def run_mixed(perturb):
+    """BASELINE.json configs[4] at full size: 26x26x123-cube bar (half NH, half StVK tets) + 158x158 sym-plane cloth
+    (triangle strain + bend) + anchors, exactly as bench.py --config mixed builds it (admm-elastic-sca_amd make_mixed_system)."""
+    from make_golden import pkg
+    desc = pkg.make_mixed_system(26, 26, 123, 158, 158, device_id=-1)[1]
+    t0 = time.time()
+    r = Ref(); r.settings(0.04, 20)
+    r.add_nodes(desc["X"].ravel(), np.repeat(desc["M"], 3))
+    for name, idx, par in desc["forces"]:
+        r.add_forces(KIND[name], idx, par)
+    r.add_gravity([0, -9.8, 0])
+    assert r.initialize()
+    if perturb:
+        xx = r.x
+        r.x = xx * (1 + perturb * np.random.default_rng(5).choice([-1.0, 1.0], size=xx.size))
+    t1 = time.time()
+    r.step()
+    t2 = time.time()
+    x = r.x.copy().reshape(-1, 3)
+    print("mixed, perturb %g: initialize %.0f s, one frame (20 iterations) %.0f s" % (perturb, t1 - t0, t2 - t1), flush=True)
+    del r
+    return x, t1 - t0, t2 - t1
+
+
+def main_mixed():
+    xa, t_init, t_step = run_mixed(0.0)
+    xb, _, _ = run_mixed(2e-16)
+    sens = float(np.abs(xa - xb).max())
+    np.savez_compressed(os.path.join(HERE, "traj_mixed_full.npz"), bar_dims=np.array([26, 26, 123]), cloth=np.array([158, 158]), stride=STRIDE, iters=20, dt=0.04,
+                        x_sample=xa[::STRIDE], sum_abs=float(np.abs(xa).sum()), sum_sq=float((xa * xa).sum()), n_nodes=xa.shape[0],
+                        ulp_sensitivity=sens, ref_initialize_s=t_init, ref_frame_s=t_step)
+    print("mixed: 1-ulp sensitivity after one frame: %.3e (max |x| %.3f)" % (sens, np.abs(xa).max()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "mixed":
+        return main_mixed()
     xa, t_init, t_step = run(0.0)
     np.savez_compressed(os.path.join(HERE, "traj_bar_1M_partial.npz"), x=xa[::STRIDE])          # keep something if the second run dies
     xb, _, _ = run(2e-16)

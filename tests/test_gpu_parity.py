@@ -529,6 +529,25 @@ def test_full_size_bar_vs_compiled_reference(pkg):
     assert abs((x * x).sum() - float(g["sum_sq"])) < bound * x.size
 
 
+def test_full_size_mixed_vs_compiled_reference(pkg):
+    """BASELINE.json configs[4] at full size (498,888 NH + StVK tets, 99,856 cloth triangles, 149k hinges, anchors) against the
+    compiled reference after one frame of 20 iterations (tests/golden/traj_mixed_full.npz, make_golden_fullsize.py mixed):
+    every force kernel of the scene at scale, bounded by 20 x the reference's own 1-ulp sensitivity."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_mixed_full.npz")):
+        pytest.skip("full-size fixture not generated")
+    g = golden("traj_mixed_full.npz")
+    s = pkg.make_mixed_system(*[int(v) for v in g["bar_dims"]], *[int(v) for v in g["cloth"]])[0]
+    s.initialize()
+    assert s.n_nodes == int(g["n_nodes"])
+    s.step(int(g["iters"]))
+    x = s.m_x.reshape(-1, 3)
+    bound = max(1e-9, 20.0 * float(g["ulp_sensitivity"]))
+    err = np.abs(x[::int(g["stride"])] - g["x_sample"]).max()
+    assert err < bound, (err, bound)
+    assert abs(np.abs(x).sum() - float(g["sum_abs"])) < bound * x.size
+
+
 def test_full_size_mixed_scene_properties(pkg):
     """BASELINE.json configs[4] at full size (498,888 NH+StVK tets, 99,856 triangles, 149k hinges, anchors; two
     disconnected bodies in one factorization): every force kernel in one step -- size-independent properties."""
