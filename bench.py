@@ -89,6 +89,37 @@ def cpu_baseline(dims):
                       "%.1f ms/iter" % (nx, ny, nz, tets.shape[0], frames, ADMM_ITERS, t_init, 1e3 * sec / (frames * ADMM_ITERS))}
 
 
+def make_rccl_hook(torch, dist, rank, world, local_rank):
+    """ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream) through ctypes on the librccl torch ships; the
+    ncclUniqueId travels from rank 0 through the torch process group.  Returns the hook admm_hip_set_allreduce expects."""
+    import ctypes
+
+    class UID(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_byte * 128)]
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rccl = ctypes.CDLL(path)
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UID)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UID, ctypes.c_int]
+    rccl.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    uid = UID()
+    if rank == 0 and rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(torch.device("cuda", local_rank))
+    dist.broadcast(t, src=0)
+    raw = t.cpu().numpy().tobytes()
+    ctypes.memmove(ctypes.byref(uid), raw, 128)
+    comm = ctypes.c_void_p()
+    rc = rccl.ncclCommInitRank(ctypes.byref(comm), dist.get_world_size(), uid, rank)
+    if rc != 0 or not comm.value:
+        raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+    NCCL_DOUBLE, NCCL_SUM = 8, 0
+
+    def hook(ptr, count, strm):
+        return 0 if rccl.ncclAllReduce(ptr, ptr, count, NCCL_DOUBLE, NCCL_SUM, comm, strm) == 0 else 1
+    hook.keep = (rccl, comm)
+    return hook
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -108,7 +139,8 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    fake_dist = fake_world > 1 and os.environ.get("ADMM_BENCH_FAKE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or fake_dist:    # (fake_dist: a 1-rank RCCL group under torchrun whose all-reduce the fake-world run really calls -- wrong sums, real mechanics)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -129,10 +161,9 @@ def main():
     else:
         s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0")) if fake_world > 1 else rank,
                                 world=fake_world if fake_world > 1 else world, stream=stream.cuda_stream, shard_mode=a.shard)
-    if fake_world > 1:
-        s_fake_rank = int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0"))
+    if fake_world > 1 and not fake_dist:
         s.set_allreduce(lambda ptr, count, strm: 0)
-    if world > 1:
+    if world > 1 or fake_dist:
         n3 = None
         holder = {}
 
@@ -140,13 +171,24 @@ def main():
             def __init__(self, ptr, count):
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
-        def hook(ptr, count, strm):
+        def torch_hook(ptr, count, strm):
             t = holder.get(ptr)
             if t is None:
                 t = torch.as_tensor(_Ptr(ptr, count), device=torch.device("cuda", local_rank))
                 holder[ptr] = t
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return 0
+        hook = torch_hook
+        # RCCL called directly on the solver's stream (ctypes -> ncclAllReduce, in place): torch.distributed's all_reduce costs
+        # ~0.25 ms of host time per call (dispatcher, work object, stream events) -- as much as a whole ADMM iteration takes at
+        # 8 GPUs.  The communicator is bootstrapped through the torch process group; any failure falls back to the torch hook.
+        if backend == "nccl" and os.environ.get("ADMM_BENCH_TORCH_ALLREDUCE") != "1":
+            try:
+                hook = make_rccl_hook(torch, dist, rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    print("bench: direct RCCL all-reduce unavailable (%r), using torch.distributed" % (e,), file=sys.stderr)
+                hook = torch_hook
         s.set_allreduce(hook)
     s.initialize()
     t_init = time.time() - t0
@@ -253,6 +295,8 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s x elements", "cores": 0, "kind": "unavailable", "sample": repr(e)}
         print(json.dumps(out))
+    if fake_dist and world == 1:
+        dist.destroy_process_group()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
