@@ -704,3 +704,26 @@ def test_device_log_exp_bitwise(pkg, hm):
         bad = np.nonzero(got.view(np.int64)[ok] != ref.view(np.int64)[ok])[0]
         assert bad.size == 0, (op, bad.size, x[ok][bad[:5]], got[ok][bad[:5]], ref[ok][bad[:5]])
         assert np.all(np.isnan(got[~ok]))
+
+
+def test_rhs_slot_layouts_agree_bitwise(pkg, monkeypatch):
+    """The RHS slots are laid out rank-major (default) or node-sorted (fallback for meshes with a few very high-valence nodes,
+    ADMM_HIP_SLOTS_NODE_SORTED=1): same per-node summation order, so the trajectories must be bitwise identical -- with the
+    panel sweeps and with the small-system inverse, residual tracking included (it shares the layout)."""
+    out = []
+    for env in (None, "1"):
+        if env is None:
+            monkeypatch.delenv("ADMM_HIP_SLOTS_NODE_SORTED", raising=False)
+        else:
+            monkeypatch.setenv("ADMM_HIP_SLOTS_NODE_SORTED", env)
+        s = pkg.make_mixed_system(5, 4, 11, 9, 7)[0]
+        s.initialize()
+        s.enable_residuals(True)
+        xs = []
+        for _ in range(3):
+            s.step(8); xs.append(s.m_x.copy())
+        r, d, _n = s.residuals()
+        out.append((xs, np.array(r), np.array(d)))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
