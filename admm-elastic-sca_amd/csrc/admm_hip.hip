@@ -238,7 +238,10 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // Larger dissection leaves = fewer elimination-tree levels (each costs >= 7-10 us per sweep whatever its size) for a little
         // more fill.  Measured (tools/leaf_sweep.py, us per ADMM iteration, leaf 16 / 64 / 128 / 256): 18.8k nodes 266 / 251 / 235 / 229,
         // 44k nodes 334 / 318 / 321 / 322, 178.6k nodes 982 / 954 / 1026 / 1020.
-        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->n_nodes < 25000 ? 256 : 64);
+        // Under subtree sharding what counts is a rank's share: 8 ranks of the 178.6k-node bar (22k nodes each) run 4 % faster with
+        // leaves of 128 (per-rank kernel time 0.438 -> 0.421 ms, tools/fake_world.sh with ADMM_HIP_LEAF), 4 ranks are indifferent.
+        const int64_t share = ctx->n_nodes / std::max(1, ctx->world);
+        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->world > 1 ? (share < 25000 ? 128 : 64) : (ctx->n_nodes < 25000 ? 256 : 64));
         // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
         int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
