@@ -65,6 +65,7 @@ struct Explicit {
 struct LevelDev {
     int n_small = 0; admm_dev::SweepItem *d_small = nullptr;   // forward: wave items (levels below the split)
     int n_big = 0; admm_dev::SweepItem *d_big = nullptr;       // forward: block items
+    int n_root = 0; admm_dev::SweepItem *d_root = nullptr;     // forward: tiles of roots solved with their explicit inverse (no backward items)
     int n_bwd = 0, bwd_cw = 1; admm_dev::SweepItem *d_bwd = nullptr;
 };
 
@@ -108,6 +109,7 @@ struct admm_hip_ctx {
     int *d_comm_top = nullptr, *d_comm_slots = nullptr; unsigned char *d_comm_mine = nullptr, *d_base_mask = nullptr, *d_keep_mask = nullptr;
     double *d_comm_buf = nullptr;
     // small systems: explicit inverse of the scalar system (factor order), one kernel per solve
+    bool root_inverse = true;                 // roots of the elimination tree: forward + backward as one product with (L L^T)^-1 (ADMM_HIP_ROOT_INVERSE=0: two sweeps)
     int dense_max = 2048; bool dense = false; std::vector<double> Ainv; double *d_ainv = nullptr;
     // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
     // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
@@ -403,7 +405,7 @@ int upload_factor(admm_hip_ctx *ctx) {
     for (int pass = 0; pass < (subtree ? 2 : 1); ++pass) {      // pass 0: this rank's supernodes (all of them without subtree sharding), pass 1: the replicated top
         for (size_t l = 0; l < F.levels.size(); ++l) {
             LevelDev &L = pass == 0 ? ctx->levels[l] : ctx->levels_top[l];
-            std::vector<admm_dev::SweepItem> sm, bg, bw;
+            std::vector<admm_dev::SweepItem> sm, bg, bw, rt;
             L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
             for (int s : F.levels[l]) {
                 if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
@@ -413,12 +415,18 @@ int upload_factor(admm_hip_ctx *ctx) {
                 it.panel_off = S.panel_off; it.front_off = S.front_off; it.slot_off = S.slot_off; it.rows_off = S.rows_off;
                 const int f = S.ncols + S.nrows;
                 const int tiles = (f + 63) / 64;
+                if (S.root_inv_off >= 0 && ctx->root_inverse) {      // a root: x = (L L^T)^-1 t in the forward sweep, nothing in the backward sweep
+                    admm_dev::SweepItem ri = it;
+                    ri.panel_off = S.root_inv_off; ri.pad = 1;
+                    for (int t = 0; t < tiles; ++t) { ri.part = t; rt.push_back(ri); }
+                    continue;
+                }
                 for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
                 const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
                 for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
             }
-            L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
-            TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
+            L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size(); L.n_root = (int)rt.size();
+            TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw)); TRY(upload(ctx, &L.d_root, rt));
         }
     }
     // subtree sharding: the exchange lists (see shard_pack_kernel) and the node masks
@@ -659,6 +667,10 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
                 if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
                 else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
+            if (L.n_root) {      // roots: both sweeps as one product with the explicit inverse, straight into x
+                if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_root), dim3(1024), 0, ctx->stream, L.d_root, F, ctx->d_y, ctx->d_xcur, ctx->d_c);
+                else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_root), dim3(1024), 0, ctx->stream, L.d_root, F, ctx->d_y, ctx->d_xcur, ctx->d_c);
+            }
         }
     };
     auto backward = [&](const std::vector<LevelDev> &levels) {
@@ -806,6 +818,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
     if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_DENSE_MAX")) ctx->dense_max = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_ROOT_INVERSE")) ctx->root_inverse = atoi(g) != 0;
     *out = ctx;
     return ADMM_OK;
 }

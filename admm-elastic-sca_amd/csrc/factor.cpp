@@ -407,6 +407,30 @@ int factorize(const SymCSC &A, Factor &F, int threads) {
         for (int s = 0; s < ns; ++s) if (is_top[s]) do_front(N, s, loc, (F.sn[s].ncols + F.sn[s].nrows >= 384) ? threads : 1);
     }
     for (int s = 0; s < ns; ++s) if (N.front[s]) { N.pool.put(N.front[s], N.front_cap[s]); N.front[s] = nullptr; }
+    // A root's two sweeps are y = L^-1 t followed at once by x = L^-T y: the GPU does them as ONE dense product with
+    // (L L^T)^-1 = L^-T L^-1 (k x k, symmetric, stored full) -- one launch instead of two at the top of the tree, where every
+    // launch is latency.  Appended to the panels (so uploads and re-factorizations carry it along).
+    if (!N.fail) {
+        for (int s = 0; s < ns; ++s) {
+            Supernode &S = F.sn[s];
+            S.root_inv_off = -1;
+            if (S.parent >= 0 || S.nrows != 0 || S.ncols <= ROOT_INV_MIN_COLS) continue;
+            const int k = S.ncols;
+            const size_t off = F.panels.size();
+            F.panels.resize(off + (size_t)k * k);
+            const double *Li = F.panels.data() + S.panel_off;      // L^-1, lower triangular, ld = k
+            double *Si = F.panels.data() + off;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+            for (int j = 0; j < k; ++j)
+                for (int i = j; i < k; ++i) {                      // S^-1(i, j) = sum_{m >= i} L^-1(m, i) L^-1(m, j)
+                    double acc = 0.0;
+                    const double *ci = Li + (size_t)k * i, *cj = Li + (size_t)k * j;
+                    for (int m = i; m < k; ++m) acc += ci[m] * cj[m];
+                    Si[i + (size_t)k * j] = acc; Si[j + (size_t)k * i] = acc;
+                }
+            S.root_inv_off = (int64_t)off;
+        }
+    }
     F.t_numeric = now_s() - t0;
     return N.fail;
 }

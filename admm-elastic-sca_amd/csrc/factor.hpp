@@ -34,14 +34,16 @@ struct Supernode {
     int64_t panel_off = 0;  // into Factor::panels (doubles), ld = ncols + nrows
     int64_t slot_off = 0;   // first contribution slot
     int64_t front_off = 0;  // index of the supernode's first front row (k + r rows) in the global front-row numbering
+    int64_t root_inv_off = -1; // roots with more than ROOT_INV_MIN_COLS columns: offset in Factor::panels of (L_ss L_ss^T)^-1, k x k, full, column-major
 };
+constexpr int ROOT_INV_MIN_COLS = 64;
 
 struct Factor {
     int n = 0;
     std::vector<int> perm, iperm;          // perm[new] = old, iperm[old] = new
     std::vector<Supernode> sn;             // postorder: children before parents
     std::vector<int> rows;                 // concatenated R_s (new indices, ascending)
-    std::vector<double> panels;            // concatenated P_s
+    std::vector<double> panels;            // concatenated P_s, then the roots' explicit inverses (Supernode::root_inv_off)
     std::vector<std::vector<int>> levels;  // supernodes per level (level 0 = leaves)
     std::vector<int64_t> cg_ptr;           // per front row (front_off[s] + i): range into cg_slot
     std::vector<int> cg_slot;              // the CHILDREN's contribution slots that land on that front row (child order)

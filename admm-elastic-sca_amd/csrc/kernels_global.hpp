@@ -357,9 +357,11 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__
     const int i = tile * 64 + lane;
     const bool row_ok = i < f;
     const double *P = F.panels + it.panel_off + (row_ok ? i : 0);
-    const int jend = (i < k) ? i + 1 : k;
+    // it.pad != 0: a root's explicit inverse (L L^T)^-1 -- full rows, and the caller passes x as W: forward and backward in one product
+    const bool full = it.pad != 0;
+    const int jend = (full || i >= k) ? k : i + 1;
     // columns beyond the tile's last row never contribute to a tile inside the triangle
-    const int kneed = min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
+    const int kneed = full ? k : min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
     // the carry of the tile's rows does not depend on this supernode: request it first
     double carry = 0.0;
     if (threadIdx.x < 192) {
