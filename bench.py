@@ -116,7 +116,11 @@ def make_rccl_hook(torch, dist, rank, world, local_rank):
 
     def hook(ptr, count, strm):
         return 0 if rccl.ncclAllReduce(ptr, ptr, count, NCCL_DOUBLE, NCCL_SUM, comm, strm) == 0 else 1
+    def close():
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
     hook.keep = (rccl, comm)
+    hook.close = close
     return hook
 
 
@@ -295,6 +299,9 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s x elements", "cores": 0, "kind": "unavailable", "sample": repr(e)}
         print(json.dumps(out))
+    if (world > 1 or fake_dist) and hasattr(hook, "close"):     # our own RCCL communicator, before the process group goes
+        torch.cuda.synchronize()
+        hook.close()
     if fake_dist and world == 1:
         dist.destroy_process_group()
     if world > 1:
