@@ -215,8 +215,24 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
     dims = (5, 4, 30)
     def mixed(rank, w):     # two disconnected bodies (two elimination-tree roots), five force kinds
         return pkg.make_mixed_system(4, 3, 12, 10, 8, rank=rank, world=w)[0]
+    from scipy.spatial import Delaunay                      # an unstructured mesh: corotational tets (no truncated minimiser -> tight)
+    prng = np.random.default_rng(7)
+    pts = prng.uniform(0, 1, size=(900, 3)) * np.array([1.0, 1.0, 3.0])
+    dt_tets = Delaunay(pts).simplices.astype(np.int32)
+    vol = np.abs(np.einsum("ij,ij->i", pts[dt_tets[:, 1]] - pts[dt_tets[:, 0]], np.cross(pts[dt_tets[:, 2]] - pts[dt_tets[:, 0]], pts[dt_tets[:, 3]] - pts[dt_tets[:, 0]]))) / 6.0
+    dt_tets = dt_tets[vol > 1e-3 * vol.mean()]
+
+    def delaunay(rank, w):
+        s = pkg.System(device_id=0); s.set_timestep(0.02)
+        s.add_nodes(pts.ravel(), np.full(3 * pts.shape[0], 1.0 / pts.shape[0]))
+        s.add_forces(pkg.KIND["TET_LINEAR"], dt_tets, [50.0])
+        s.add_forces(pkg.KIND["ANCHOR"], np.nonzero(pts[:, 2] < 0.2)[0].astype(np.int32), [-1.0, 1.0])
+        s.add_gravity([0, -9.8, 0])
+        if w > 1:
+            s.set_shard(rank, w)
+        return s
     for name, make, tol in (("cloth", cloth, 1e-9), ("bar", lambda r, w: pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=w), 1e-5),
-                            ("mixed", mixed, 1e-5)):
+                            ("mixed", mixed, 1e-5), ("delaunay", delaunay, 1e-9)):
         ref = make(0, 1)
         ref.initialize()
         shards = [make(r, world) for r in range(world)]
