@@ -136,6 +136,39 @@ def test_subtree_partition_properties(pkg, monkeypatch, world):
     assert loads.sum() == t.shape[0] + anchors.size and loads.max() < 1.6 * loads.mean()
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_subtree_partition_unstructured(pkg, monkeypatch, world):
+    """The same properties on an unstructured mesh (Delaunay tets of random points: 5-60 tets per node)."""
+    from scipy.spatial import Delaunay
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 1, size=(3000, 3)) * np.array([1.0, 1.0, 3.0])
+    t = Delaunay(pts).simplices.astype(np.int32)
+    vol = np.abs(np.einsum("ij,ij->i", pts[t[:, 1]] - pts[t[:, 0]], np.cross(pts[t[:, 2]] - pts[t[:, 0]], pts[t[:, 3]] - pts[t[:, 0]]))) / 6.0
+    t = t[vol > 1e-3 * vol.mean()]
+    systems = []
+    for r in range(world):
+        s = pkg.System(device_id=-1); s.set_timestep(0.02)
+        s.add_nodes(pts.ravel(), np.full(3 * pts.shape[0], 1e-3))
+        s.add_forces(pkg.KIND["TET_LINEAR"], t, [50.0])
+        s.set_shard(r, world); s.set_shard_mode("subtree")
+        s.initialize()
+        systems.append(s)
+    owner = systems[0].node_owner()
+    assert all(np.array_equal(s.node_owner(), owner) for s in systems[1:])
+    assert owner.min() == -1 and owner.max() == world - 1 and (owner == -1).mean() < 0.5
+    seen = np.zeros(t.shape[0], np.int32)
+    for r, s in enumerate(systems):
+        ids = s.local_elements(0)
+        seen[ids] += 1
+        o = owner[t[ids]]
+        assert np.all((o == r) | (o == -1))
+    assert np.all(seen == 1)
+    loads = np.array([s.info()["n_elems_local"] for s in systems], dtype=float)
+    assert loads.max() < 1.6 * loads.mean()
+
+
 def _thread_allreduce_hooks(world):
     """all-reduce between `world` contexts living in ONE process on ONE GPU (threads meeting at barriers)"""
     import torch
