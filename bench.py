@@ -109,13 +109,35 @@ def make_rccl_hook(torch, dist, rank, world, local_rank):
     raw = t.cpu().numpy().tobytes()
     ctypes.memmove(ctypes.byref(uid), raw, 128)
     comm = ctypes.c_void_p()
-    rc = rccl.ncclCommInitRank(ctypes.byref(comm), dist.get_world_size(), uid, rank)
-    if rc != 0 or not comm.value:
-        raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+    # the collective init runs in a thread with a deadline, and every rank learns whether ALL ranks succeeded (MIN over the torch
+    # group): either everybody uses the direct path or everybody falls back -- never a mix, which would deadlock
+    import threading
+    state = {"rc": None}
+
+    def init():
+        state["rc"] = rccl.ncclCommInitRank(ctypes.byref(comm), dist.get_world_size(), uid, rank)
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(timeout=float(os.environ.get("ADMM_BENCH_RCCL_INIT_TIMEOUT", "120")))
     NCCL_DOUBLE, NCCL_SUM = 8, 0
 
     def hook(ptr, count, strm):
         return 0 if rccl.ncclAllReduce(ptr, ptr, count, NCCL_DOUBLE, NCCL_SUM, comm, strm) == 0 else 1
+    good = state["rc"] == 0 and bool(comm.value)
+    flag = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) < 1.0:
+        raise RuntimeError("ncclCommInitRank failed or timed out on some rank (here: rc %r)" % (state["rc"],))
+    # one checked all-reduce through the new communicator: 1 + 2 + ... + world
+    probe = torch.full((8,), float(rank + 1), dtype=torch.float64, device=torch.device("cuda", local_rank))
+    rc = hook(probe.data_ptr(), probe.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = dist.get_world_size() * (dist.get_world_size() + 1) / 2.0
+    flag.fill_(1.0 if (rc == 0 and bool((probe == want).all().item())) else 0.0)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) < 1.0:
+        raise RuntimeError("direct ncclAllReduce check failed")
+
     def close():
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
