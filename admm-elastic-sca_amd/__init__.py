@@ -65,7 +65,7 @@ def build(force=False, verbose=False):
 
 
 def lib():
-    """Loads libadmm_hip.so (building it if absent).  Raises if it cannot be loaded."""
+    """Loads libadmm_hip.so (rebuilding it when a source is newer: build() checks mtimes).  Raises if it cannot be loaded."""
     global _lib
     if _lib is None:
         # One HIP runtime per process: PyTorch bundles its own libamdhip64; importing it
@@ -76,8 +76,8 @@ def lib():
         except Exception:
             pass
         path = os.environ.get("ADMM_HIP_LIB", LIB_PATH)   # experimental variants (tools/ab_local.py)
-        if not os.path.exists(path):
-            build()
+        if path == LIB_PATH or not os.path.exists(path):
+            build()     # no-op when the library is newer than every source (a stale library after an edit is worse than 0.1 s of stat calls)
         L = C.CDLL(path)
         L.admm_hip_last_error.restype = C.c_char_p
         L.admm_hip_last_error.argtypes = [C.c_void_p]

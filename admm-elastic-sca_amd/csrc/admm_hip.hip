@@ -1026,7 +1026,6 @@ int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets,
         if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, tg.data(), sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
         if (active) HIPCHK(hipMemcpyAsync(b.d_active, ac.data(), sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     return ADMM_OK;
 }
@@ -1065,12 +1064,13 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     if (track) TRY(ensure_residual_buffers(ctx, admm_iters));
     const bool use_graph = ctx->graph_enabled && ctx->world == 1 && !ctx->timing && !track && admm_iters > 0;
     if (use_graph && !ctx->iter_exec) {   // capture one iteration; every kernel argument is a fixed device address
-        HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        int rc = launch_local(ctx);
+        // a stream that cannot be captured (caller-supplied, already capturing ...) is not an error: launch eagerly instead
+        const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        int rc = be == hipSuccess ? launch_local(ctx) : ADMM_ERR_HIP;
         if (!rc) rc = launch_rhs(ctx);
         if (!rc) rc = launch_solve(ctx, nullptr);
         hipGraph_t g = nullptr;
-        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+        const hipError_t ce = be == hipSuccess ? hipStreamEndCapture(ctx->stream, &g) : be;
         if (rc || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); ctx->graph_enabled = false; fprintf(stderr, "admm_hip: graph capture unavailable, launching eagerly\n"); }
         else {
             ctx->iter_graph = g;

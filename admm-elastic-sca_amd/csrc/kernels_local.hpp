@@ -92,23 +92,6 @@ __device__ __forceinline__ void st_stream(double *p, double v) {
 #endif
 }
 
-// write a block's per-corner contributions (NV doubles per lane) through LDS
-// so that global stores are contiguous: out[(e0 + t) * NV + i]
-template <int NV>
-__device__ __forceinline__ void store_block_contiguous(double *lds, const double (&vals)[NV], double *out, int e0, int n_valid) {
-    constexpr int PAD = NV + 1;
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) lds[t * PAD + i] = vals[i];
-    __syncthreads();
-    const int total = n_valid * NV;
-    double *base = out + (size_t)e0 * NV;
-    for (int q = t; q < total; q += LOCAL_BLOCK) {
-        const int e = q / NV, i = q - e * NV;
-        base[q] = lds[e * PAD + i];
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Tets: KIND 0 = Neo-Hookean, 1 = StVK (HyperElasticTet, TetForce.cpp:320-364),
 //       2 = LinearTetStrain (:127-153), 3 = TetVolume (:173-210)

@@ -27,9 +27,6 @@
 #ifndef ADMM_REUSE_GRAD
 #define ADMM_REUSE_GRAD 1   // reuse bitwise-identical gradient evaluations (see mt_linesearch)
 #endif
-#ifndef ADMM_HISTORY_REG
-#define ADMM_HISTORY_REG 0  // 1: L-BFGS history in registers, 0: in private (scratch) memory
-#endif
 
 namespace admm_dev {
 
@@ -637,78 +634,6 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
     return globIter;
 }
 
-// ---- variant with the history in registers (unrolled selects)
-// M = compile-time history capacity (>= min(maxIter,10)); history lives in
-// registers, run-time positions are resolved by unrolled selects.
-template <int M, class P> ADMM_HD int lbfgs_minimize_reg(const P &prob, V3 &x0, int maxIter, double gradTol, double &init_hess) {
-    const int m_ = maxIter < 10 ? maxIter : 10;
-    const double eps_g = gradTol, eps_x = 1e-8;
-    V3 s[M], y[M];
-    double alpha[M], rho[M];
-#pragma unroll
-    for (int i = 0; i < M; ++i) { s[i].a = s[i].b = s[i].c = 0.0; y[i].a = y[i].b = y[i].c = 0.0; alpha[i] = 0.0; rho[i] = 0.0; }
-    V3 grad = prob.gradient(x0);
-    double gamma_k = init_hess;
-    double alpha_init = smin(1.0, 1.0 / absmax(grad));
-    int globIter = 0;
-    int maxiter = maxIter;
-    double new_hess_guess = 1.0;
-    for (int k = 0; k < maxiter; k++) {
-        V3 x_old = x0, grad_old = grad, q = grad;
-        globIter++;
-        const int iter = m_ < k ? m_ : k;
-#pragma unroll
-        for (int i = M - 1; i >= 0; --i) {
-            if (i < iter) {
-                rho[i] = 1.0 / dotd(s[i], y[i]);
-                alpha[i] = rho[i] * dotd(s[i], q);
-                q.a = q.a - alpha[i] * y[i].a; q.b = q.b - alpha[i] * y[i].b; q.c = q.c - alpha[i] * y[i].c;
-            }
-        }
-        q.a = gamma_k * q.a; q.b = gamma_k * q.b; q.c = gamma_k * q.c;
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            if (i < iter) {
-                double beta = rho[i] * dotd(q, y[i]);
-                double ab = alpha[i] - beta;
-                q.a = q.a + ab * s[i].a; q.b = q.b + ab * s[i].b; q.c = q.c + ab * s[i].c;
-            }
-        }
-        double dir = dotd(q, grad);
-        if (dir < 1e-4) {
-            q = grad;
-            maxiter -= k;
-            k = 0;
-            alpha_init = smin(1.0, 1.0 / absmax(grad));
-        }
-        V3 mq; mq.a = -q.a; mq.b = -q.b; mq.c = -q.c;
-        V3 g_new; bool have_g;
-        const double rate = mt_linesearch(prob, x0, mq, alpha_init, grad, g_new, have_g);
-        x0.a = x0.a - rate * q.a; x0.b = x0.b - rate * q.b; x0.c = x0.c - rate * q.c;
-        V3 dxx; dxx.a = x_old.a - x0.a; dxx.b = x_old.b - x0.b; dxx.c = x_old.c - x0.c;
-        if (dotd(dxx, dxx) < eps_x) break;
-        grad = (ADMM_REUSE_GRAD && have_g) ? g_new : prob.gradient(x0);
-        double gradNorm = absmax(grad);
-        if (gradNorm < eps_g) { new_hess_guess = gamma_k; break; }
-        V3 s_temp, y_temp;
-        s_temp.a = x0.a - x_old.a; s_temp.b = x0.b - x_old.b; s_temp.c = x0.c - x_old.c;
-        y_temp.a = grad.a - grad_old.a; y_temp.b = grad.b - grad_old.b; y_temp.c = grad.c - grad_old.c;
-        if (k < m_) {
-#pragma unroll
-            for (int i = 0; i < M; ++i) if (i == k) { s[i] = s_temp; y[i] = y_temp; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < M - 1; ++i) if (i < m_ - 1) { s[i] = s[i + 1]; y[i] = y[i + 1]; }
-#pragma unroll
-            for (int i = 0; i < M; ++i) if (i == m_ - 1) { s[i] = s_temp; y[i] = y_temp; }
-        }
-        gamma_k = dotd(s_temp, y_temp) / dotd(y_temp, y_temp);
-        alpha_init = 1.0;
-    }
-    init_hess = new_hess_guess;
-    return globIter;
-}
-
 // ---- HyperElasticTet::project on F = Dx_i + u_i, CORE/TetForce.cpp:320-364 ----
 // state: sa,sb,sc = last_prox_result, hess = solver->settings_.init_hess.
 // Returns z (= U diag(sigma) V^T) and the L-BFGS iteration count.
@@ -724,11 +649,7 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     V3 x2; x2.a = sa; x2.b = sb; x2.c = sc;
     if (x2.c < 0.0) x2.c *= -1.0;
     else if (fabs(x2.a) < 1.e-3 && fabs(x2.b) < 1.e-3 && fabs(x2.c) < 1.e-3) { x2.a = 1.e-3; x2.b = 1.e-3; x2.c = 1.e-3; }
-#if ADMM_HISTORY_REG
-    n_iters = lbfgs_minimize_reg<M>(P, x2, maxIter, 1e-8, hess);
-#else
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
-#endif
     sa = x2.a; sb = x2.b; sc = x2.c;
     ADMM_PROF_TIME(2);
 #if ADMM_PROF_ON
