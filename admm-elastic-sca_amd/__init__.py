@@ -32,6 +32,8 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+PROJECT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_int64, _dp, _dp, _dp)
+KIND_GENERIC = 11
 
 
 class Info(C.Structure):
@@ -118,6 +120,15 @@ def lib():
         L.admm_hip_apply_A.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_panel_solve_host.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp]
+        L.admm_hip_add_generic_batch.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int64, _ip, _ip, _dp, _dp, C.POINTER(C.c_int)]
+        L.admm_hip_set_project_hook.argtypes = [C.c_void_p, PROJECT_FN, C.c_void_p]
+        L.admm_hip_rccl_unique_id.argtypes = [C.c_void_p]
+        L.admm_hip_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.admm_hip_set_rccl_comm.argtypes = [C.c_void_p, C.c_void_p]
+        L.admm_hip_debug_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.admm_hip_pin_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.admm_hip_upload_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.admm_hip_download_state.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.admm_hip_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
@@ -187,6 +198,62 @@ class System:
         self._chk(self.L.admm_hip_add_batch(self.h, kind, n, _i(idx), _d(params), _d(tg), C.byref(b)))
         self.batches.append((kind, n))
         return b.value
+
+    def add_generic(self, elem_row_ptr, trip_row, trip_col, trip_val, row_weight):
+        """A run of user-defined forces (admm_hip_add_generic_batch): selector rows as triplets (row relative to the batch,
+        col = 3 * node + component), one weight per row; project() is the hook installed with set_project_hook."""
+        erp = np.ascontiguousarray(elem_row_ptr, dtype=np.int32)
+        tr = np.ascontiguousarray(trip_row, dtype=np.int32); tc = np.ascontiguousarray(trip_col, dtype=np.int32)
+        tv = np.ascontiguousarray(trip_val, dtype=np.float64); rw = np.ascontiguousarray(row_weight, dtype=np.float64)
+        assert tr.size == tc.size == tv.size and rw.size == erp[-1]
+        b = C.c_int()
+        self._chk(self.L.admm_hip_add_generic_batch(self.h, erp.size - 1, _i(erp), tr.size, _i(tr), _i(tc), _d(tv), _d(rw), C.byref(b)))
+        self.batches.append((KIND_GENERIC, erp.size - 1))
+        self._generic_rows = getattr(self, "_generic_rows", {})
+        self._generic_rows[b.value] = np.diff(erp)
+        return b.value
+
+    def set_project_hook(self, pyfunc):
+        """pyfunc(dt, Dx, u, z): numpy views over ALL generic rows; update u and z in place (Force::project, System.cpp:57-58)."""
+        def tramp(user, dt, n_rows, dx, u, z):
+            try:
+                n = int(n_rows)
+                pyfunc(float(dt), np.ctypeslib.as_array(dx, shape=(n,)), np.ctypeslib.as_array(u, shape=(n,)), np.ctypeslib.as_array(z, shape=(n,)))
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("project hook raised:", e)
+                return 1
+        self._pcb = PROJECT_FN(tramp)
+        self._chk(self.L.admm_hip_set_project_hook(self.h, self._pcb, None))
+
+    # ---- RCCL inside the library (admm_hip.h "RCCL inside the library") ----
+    def rccl_unique_id(self):
+        buf = np.zeros(128, np.uint8)
+        rc = self.L.admm_hip_rccl_unique_id(buf.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise AdmmHipError("admm_hip_rccl_unique_id failed (%d)" % rc)
+        return buf
+
+    def rccl_init(self, uid, rank, world):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        assert uid.size == 128
+        self._chk(self.L.admm_hip_rccl_init(self.h, uid.ctypes.data_as(C.c_void_p), int(rank), int(world)))
+
+    def set_rccl_comm(self, comm_ptr):
+        self._chk(self.L.admm_hip_set_rccl_comm(self.h, C.c_void_p(comm_ptr) if comm_ptr else None))
+
+    def debug_allreduce(self, dev_ptr, count):
+        self._chk(self.L.admm_hip_debug_allreduce(self.h, C.c_void_p(dev_ptr), int(count)))
+
+    # ---- the class API's frame boundary (host/admm/System.hpp step()) ----
+    def pin_host(self, arr, on=True):
+        self._chk(self.L.admm_hip_pin_host(self.h, C.c_void_p(arr.ctypes.data), arr.nbytes, 1 if on else 0))
+
+    def upload_state(self, x=None, v=None):
+        self._chk(self.L.admm_hip_upload_state(self.h, _d(x), _d(v)))
+
+    def download_state(self, x=None, v=None):
+        self._chk(self.L.admm_hip_download_state(self.h, _d(x), _d(v)))
 
     def add_gravity(self, g):
         self._chk(self.L.admm_hip_add_gravity(self.h, float(g[0]), float(g[1]), float(g[2])))
@@ -316,6 +383,11 @@ class System:
 
     def read_local(self, batch):
         kind, _ = self.batches[batch]
+        if kind == KIND_GENERIC:     # u, z of this rank's user forces, element after element
+            nr = int(self._generic_rows[batch][self.local_elements(batch)].sum())
+            u = np.zeros(nr); z = np.zeros(nr)
+            self._chk(self.L.admm_hip_read_local(self.h, batch, _d(u), _d(z), None, None))
+            return dict(u=u, z=z)
         n = self.local_elements(batch).size
         rows = KIND_ROWS[kind]
         u = np.zeros((n, rows)); z = np.zeros((n, rows))

@@ -1,6 +1,7 @@
 // admm_hip.hip -- context, host orchestration and C ABI of libadmm_hip.so.
 // See include/admm_hip.h for the contract and DESIGN.md for the design.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -49,6 +50,23 @@ struct Batch {
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
     double *d_u_prev = nullptr, *d_z_prev = nullptr, *d_G = nullptr;   // residual tracking only
     std::vector<double> G;                // [12][n_local] selector block per element, corners in device order
+    // ---- ADMM_KIND_GENERIC (user-defined forces): selector rows as CSR over the batch's rows
+    std::vector<int64_t> g_elem_row;      // [n_total + 1] first batch row of every element
+    std::vector<int64_t> g_rowptr;        // [rows + 1]
+    std::vector<int32_t> g_col;           // entry columns (3 * node + component, original node ids), ascending inside a row
+    std::vector<double> g_val, g_roww;    // entry values; weight per row
+    std::vector<int64_t> g_elem_node;     // [n_total + 1]
+    std::vector<int32_t> g_nodes;         // every element's nodes, ascending
+    int64_t g_row0 = 0, g_rows = 0;       // position in the context-wide generic row space
+    int g_lrows = 0, g_lslots = 0;        // this rank's rows / (element, node) slots
+    std::vector<double> g_sval; std::vector<int32_t> g_srow_b;   // per slot entry: D value and batch row (coefficients are rebuilt on recompute_weights)
+    int *d_g_lrow = nullptr, *d_g_rptr = nullptr, *d_g_col = nullptr, *d_g_sptr = nullptr, *d_g_srow = nullptr, *d_g_sdst = nullptr;
+    double *d_g_val = nullptr, *d_g_scoef = nullptr;
+    int elem_nodes(int e, const int32_t **p) const {
+        if (kind == ADMM_KIND_GENERIC) { *p = g_nodes.data() + g_elem_node[e]; return (int)(g_elem_node[e + 1] - g_elem_node[e]); }
+        *p = idx.data() + (size_t)e * ADMM_KIND_NODES[kind]; return ADMM_KIND_NODES[kind];
+    }
+    int elem_rows(int e) const { return kind == ADMM_KIND_GENERIC ? (int)(g_elem_row[e + 1] - g_elem_row[e]) : ADMM_KIND_ROWS[kind]; }
 };
 
 struct Explicit {
@@ -79,6 +97,7 @@ struct admm_hip_ctx {
     double dt = 0.04;
     int rank = 0, world = 1;
     admm_hip_allreduce_fn allreduce = nullptr; void *allreduce_user = nullptr;
+    void *rccl_comm = nullptr; bool rccl_owned = false;      // ncclComm_t: the all-reduce is ncclAllReduce on the context's stream (takes precedence over the hook)
     bool finalized = false;
     int leaf_size = 0;                        // nested-dissection leaf size; 0 = by system size (host_factor)
     // host state
@@ -94,6 +113,7 @@ struct admm_hip_ctx {
     // device state (node arrays in factor order)
     double *d_x = nullptr, *d_v = nullptr, *d_m3 = nullptr, *d_mxbar = nullptr, *d_xcur = nullptr, *d_y = nullptr, *d_w = nullptr, *d_c = nullptr;
     double *d_fslot = nullptr; int64_t n_fslots = 0;
+    int *d_perm = nullptr; double *d_stage = nullptr;          // frame boundary: factor position -> caller's node; [2][3n] staging in the caller's order
     int slot_stride = 0;                      // > 0: RHS slots rank-major (slot of a node's r-th incidence = r * slot_stride + node), 0: node-sorted
     int64_t *d_inc_ptr = nullptr;
     double *d_panels = nullptr; int *d_sn_first = nullptr, *d_sn_ncols = nullptr, *d_sn_nrows = nullptr, *d_rows = nullptr, *d_cg_slot = nullptr, *d_cg4 = nullptr;
@@ -115,11 +135,18 @@ struct admm_hip_ctx {
     // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
     // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
     bool graph_enabled = true; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
+    bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
     // residual tracking / early exit (off by default)
     bool res_on = false, res_ready = false;
     double tol_r = 0.0, tol_s = 0.0; int check_every = 1;
     double *d_res = nullptr; int res_cap = 0, res_n = 0;      // [2 * res_cap]: r^2, s^2 per iteration
     double *d_res_slots = nullptr, *d_res_s = nullptr, *d_res_partial = nullptr; int res_partial_n = 0;
+    // user-defined forces: host round trip per ADMM iteration (see admm_hip_add_generic_batch)
+    admm_hip_project_fn project_hook = nullptr; void *project_user = nullptr;
+    int64_t n_gen_rows = 0;
+    double *d_gen_dx = nullptr, *d_gen_q = nullptr;                 // [n_gen_rows]
+    double *h_gen_dx = nullptr, *h_gen_u = nullptr, *h_gen_z = nullptr, *h_gen_q = nullptr;   // pinned
+    hipEvent_t gen_ev = nullptr;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
@@ -138,6 +165,51 @@ int fail(admm_hip_ctx *c, int code, const char *fmt, ...) {
 }
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, ADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+// ---- RCCL, bound at run time (dlopen): the library has no link-time dependency on it, single-GPU users never load it ----
+struct nccl_uid { char internal[128]; };
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(nccl_uid *) = nullptr;
+    int (*CommInitRank)(void **, int, nccl_uid, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi *rccl_api(std::string *why) {
+    static RcclApi api; static bool tried = false; static std::string err;
+    if (!tried) {
+        tried = true;
+        // the copy already in the process first (PyTorch ships its own librccl.so): two RCCL instances must not share a job
+        const char *names[] = {getenv("ADMM_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (int pass = 0; pass < 2 && !api.handle; ++pass)
+            for (const char *nm : names) { if (!nm || !*nm) continue; api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0)); if (api.handle) break; }
+        if (!api.handle) err = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "no dlerror") + "); set ADMM_HIP_RCCL_LIB";
+        else {
+            api.GetUniqueId = (int (*)(nccl_uid *))dlsym(api.handle, "ncclGetUniqueId");
+            api.CommInitRank = (int (*)(void **, int, nccl_uid, int))dlsym(api.handle, "ncclCommInitRank");
+            api.CommDestroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
+            api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+            api.GetErrorString = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce"; api.handle = nullptr; }
+        }
+    }
+    if (!api.handle) { if (why) *why = err; return nullptr; }
+    return &api;
+}
+// sum `count` doubles in place across the ranks, on the context's stream: RCCL directly when a communicator is installed
+// (admm_hip_rccl_init / admm_hip_set_rccl_comm: no host code between the kernels, capturable), otherwise the caller's hook
+int do_allreduce(admm_hip_ctx *ctx, double *buf, int64_t count) {
+    if (ctx->rccl_comm) {
+        RcclApi *R = rccl_api(nullptr);
+        const int rc = R ? R->AllReduce(buf, buf, (size_t)count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->rccl_comm, ctx->stream) : -1;
+        if (rc != 0) return fail(ctx, ADMM_ERR_COMM, "ncclAllReduce failed: %s", (R && R->GetErrorString) ? R->GetErrorString(rc) : "RCCL not loaded");
+        return ADMM_OK;
+    }
+    if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but neither an RCCL communicator nor an all-reduce hook is installed", ctx->world);
+    if (ctx->allreduce(ctx->allreduce_user, buf, count, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+    return ADMM_OK;
+}
 
 template <class T> int dalloc(admm_hip_ctx *ctx, T **p, size_t n) {
     *p = nullptr;
@@ -181,6 +253,37 @@ int idx_stride(int kind) {
     switch (kind) { case ADMM_KIND_ANCHOR: case ADMM_KIND_COLLISION: return 1; case ADMM_KIND_SPRING: return 2; default: return 4; }
 }
 
+// A user-defined element's share of A_s.  The accelerated path factors the scalar system, so dt^2 D_e^T W^2 D_e must be
+// K (x) I3: no coupling between coordinates and the same K for x, y and z.  Checked per element, refused loudly otherwise.
+int assemble_generic(admm_hip_ctx *ctx, const Batch &b, std::vector<int> &ti, std::vector<int> &tj, std::vector<double> &tv) {
+    const double dt = ctx->dt;
+    std::vector<double> K;
+    for (int e = 0; e < b.n_total; ++e) {
+        const int32_t *nodes; const int nn = b.elem_nodes(e, &nodes);
+        if (nn && nodes[nn - 1] >= ctx->n_nodes) return fail(ctx, ADMM_ERR_ARG, "user-defined force %d references node %d (have %d nodes)", e, nodes[nn - 1], ctx->n_nodes);
+        K.assign((size_t)3 * nn * nn, 0.0);
+        double cross = 0.0, kmax = 0.0;
+        for (int64_t r = b.g_elem_row[e]; r < b.g_elem_row[e + 1]; ++r) {
+            const double w = b.g_roww[r];
+            for (int64_t p = b.g_rowptr[r]; p < b.g_rowptr[r + 1]; ++p) for (int64_t q = b.g_rowptr[r]; q < b.g_rowptr[r + 1]; ++q) {
+                const int np_ = b.g_col[p] / 3, cp = b.g_col[p] % 3, nq = b.g_col[q] / 3, cq = b.g_col[q] % 3;
+                const double t = (((dt * dt) * b.g_val[p]) * w) * w * b.g_val[q];
+                if (cp != cq) { cross = std::max(cross, std::fabs(t)); continue; }
+                const int a = (int)(std::lower_bound(nodes, nodes + nn, np_) - nodes), c = (int)(std::lower_bound(nodes, nodes + nn, nq) - nodes);
+                K[((size_t)cp * nn + a) * nn + c] += t;
+            }
+        }
+        for (double v : K) kmax = std::max(kmax, std::fabs(v));
+        double dev = 0.0;
+        for (size_t i = 0; i < (size_t)nn * nn; ++i) dev = std::max(dev, std::max(std::fabs(K[i] - K[(size_t)nn * nn + i]), std::fabs(K[i] - K[2 * (size_t)nn * nn + i])));
+        if (cross > 1e-12 * kmax || dev > 1e-12 * kmax)
+            return fail(ctx, ADMM_ERR_UNSUPPORTED, "user-defined force %d of a generic batch: D^T W^2 D is not of the form K (x) I3 (coordinate coupling %.3g, x/y/z mismatch %.3g of %.3g); "
+                        "the accelerated path factors the scalar system", e, cross, dev, kmax);
+        for (int a = 0; a < nn; ++a) for (int c = 0; c <= a; ++c) { ti.push_back(nodes[a]); tj.push_back(nodes[c]); tv.push_back(K[(size_t)a * nn + c]); }
+    }
+    return ADMM_OK;
+}
+
 // ---- host part of finalize: rest data, rows, A_s, ordering, factorization ----
 int host_assemble(admm_hip_ctx *ctx, bool reuse_rest) {
     const int n = ctx->n_nodes;
@@ -194,6 +297,13 @@ int host_assemble(admm_hip_ctx *ctx, bool reuse_rest) {
         ti.push_back(i); tj.push_back(i); tv.push_back(m);
     }
     for (Batch &b : ctx->batches) {
+        if (b.kind == ADMM_KIND_GENERIC) {
+            if (!reuse_rest) b.global_idx.assign(b.n_total, 0);
+            for (int e = 0; e < b.n_total; ++e) { b.global_idx[e] = (int32_t)row; row += b.elem_rows(e); }
+            TRY(assemble_generic(ctx, b, ti, tj, tv));
+            ntot += b.n_total;
+            continue;
+        }
         const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind];
         if (!reuse_rest) {
             b.weight.assign(b.n_total, 0.0); b.rest.assign((size_t)b.n_total * 12, 0.0); b.measure.assign(b.n_total, 0.0);
@@ -352,12 +462,12 @@ void assign_elements(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;
     int64_t nloc = 0;
     for (Batch &b : ctx->batches) {
-        const int nn = ADMM_KIND_NODES[b.kind];
         b.local.clear();
         if (ctx->shard_mode == 1 && ctx->world > 1) {
             for (int e = 0; e < b.n_total; ++e) {
                 int owner = -1;
-                for (int c = 0; c < nn && owner < 0; ++c) owner = ctx->node_owner[F.iperm[b.idx[(size_t)e * nn + c]]];
+                const int32_t *nd; const int nn = b.elem_nodes(e, &nd);
+                for (int c = 0; c < nn && owner < 0; ++c) owner = ctx->node_owner[F.iperm[nd[c]]];
                 if (owner < 0) owner = e % ctx->world;      // all nodes in the replicated top: any rank will do
                 if (owner == ctx->rank) b.local.push_back(e);
             }
@@ -464,6 +574,7 @@ int upload_all(admm_hip_ctx *ctx) {
         TRY(upload(ctx, &ctx->d_x, px)); TRY(upload(ctx, &ctx->d_v, pv)); TRY(upload(ctx, &ctx->d_m3, pm));
         TRY(upload(ctx, &ctx->d_xcur, px));
         TRY(dalloc(ctx, &ctx->d_mxbar, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_y, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_w, 3 * (size_t)n));
+        TRY(upload(ctx, &ctx->d_perm, F.perm)); TRY(dalloc(ctx, &ctx->d_stage, 6 * (size_t)n));
     }
     TRY(upload_factor(ctx));
     // batches: shard, sort corners, SoA upload
@@ -471,6 +582,16 @@ int upload_all(admm_hip_ctx *ctx) {
     // pass 1: local ranges, corner order, incidence counts per (factor-order) node
     std::vector<int64_t> inc_ptr(n + 1, 0);
     for (Batch &b : ctx->batches) {
+        if (b.kind == ADMM_KIND_GENERIC) {      // one slot per (element, node)
+            b.slot_base = slot;
+            for (int el = 0; el < b.n_local; ++el) {
+                const int32_t *nd; const int nn = b.elem_nodes(b.local[el], &nd);
+                for (int c = 0; c < nn; ++c) inc_ptr[F.iperm[nd[c]] + 1]++;
+                slot += nn;
+            }
+            nloc += b.n_local;
+            continue;
+        }
         const int nn = ADMM_KIND_NODES[b.kind];
         b.slot_base = slot;
         const bool is_tri = b.kind == ADMM_KIND_TRI_STRAIN || b.kind == ADMM_KIND_TRI_AREA || b.kind == ADMM_KIND_TRI_FUNG;
@@ -499,6 +620,38 @@ int upload_all(admm_hip_ctx *ctx) {
     ctx->slot_stride = (maxdeg * n <= 2 * inc_ptr[n] + 1024 && getenv("ADMM_HIP_SLOTS_NODE_SORTED") == nullptr) ? n : 0;
     // pass 2: device arrays; every corner gets the next slot of its node (fixed order: batch, element, corner)
     for (Batch &b : ctx->batches) {
+        if (b.kind == ADMM_KIND_GENERIC) {
+            // this rank's rows (CSR in factor-order dofs) and, per (element, node) slot and component, the rows that feed it
+            std::vector<int> lrow, rptr(1, 0), col, sptr(1, 0), srow, sdst;
+            std::vector<double> val;
+            b.g_sval.clear(); b.g_srow_b.clear();
+            for (int el = 0; el < b.n_local; ++el) {
+                const int e = b.local[el];
+                const int32_t *nd; const int nn = b.elem_nodes(e, &nd);
+                for (int64_t r = b.g_elem_row[e]; r < b.g_elem_row[e + 1]; ++r) {
+                    lrow.push_back((int)(b.g_row0 + r));
+                    for (int64_t p = b.g_rowptr[r]; p < b.g_rowptr[r + 1]; ++p) { col.push_back(3 * F.iperm[b.g_col[p] / 3] + b.g_col[p] % 3); val.push_back(b.g_val[p]); }
+                    rptr.push_back((int)col.size());
+                }
+                for (int c = 0; c < nn; ++c) {
+                    const int pn = F.iperm[nd[c]];
+                    const int64_t r = inc_pos[pn]++;
+                    sdst.push_back(ctx->slot_stride ? (int)((r - inc_ptr[pn]) * ctx->slot_stride + pn) : (int)r);
+                    for (int comp = 0; comp < 3; ++comp) {
+                        for (int64_t rr = b.g_elem_row[e]; rr < b.g_elem_row[e + 1]; ++rr)
+                            for (int64_t p = b.g_rowptr[rr]; p < b.g_rowptr[rr + 1]; ++p)
+                                if (b.g_col[p] == 3 * nd[c] + comp) { srow.push_back((int)(b.g_row0 + rr)); b.g_srow_b.push_back((int32_t)rr); b.g_sval.push_back(b.g_val[p]); }
+                        sptr.push_back((int)srow.size());
+                    }
+                }
+            }
+            b.g_lrows = (int)lrow.size(); b.g_lslots = (int)sdst.size();
+            std::vector<double> coef(b.g_sval.size());
+            for (size_t i = 0; i < coef.size(); ++i) { const double w = b.g_roww[b.g_srow_b[i]]; coef[i] = b.g_sval[i] * ((ctx->dt * ctx->dt) * (w * w)); }
+            TRY(upload(ctx, &b.d_g_lrow, lrow)); TRY(upload(ctx, &b.d_g_rptr, rptr)); TRY(upload(ctx, &b.d_g_col, col)); TRY(upload(ctx, &b.d_g_val, val));
+            TRY(upload(ctx, &b.d_g_sptr, sptr)); TRY(upload(ctx, &b.d_g_srow, srow)); TRY(upload(ctx, &b.d_g_sdst, sdst)); TRY(upload(ctx, &b.d_g_scoef, coef));
+            continue;
+        }
         const int nn = ADMM_KIND_NODES[b.kind], np = ADMM_KIND_PARAMS[b.kind], rows = ADMM_KIND_ROWS[b.kind], ist = idx_stride(b.kind);
         const int nl = b.n_local;
         std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0), dst((size_t)std::max(nl, 1) * ist, 0);
@@ -555,6 +708,17 @@ int upload_all(admm_hip_ctx *ctx) {
     TRY(dalloc(ctx, &ctx->d_fslot, 3 * (size_t)std::max<int64_t>(slot, 1)));
     HIPCHK(hipMemset(ctx->d_fslot, 0, sizeof(double) * 3 * (size_t)std::max<int64_t>(slot, 1)));
     TRY(upload(ctx, &ctx->d_inc_ptr, inc_ptr));
+    if (ctx->n_gen_rows) {      // user-defined forces: device and pinned host images of the generic row space
+        const size_t bytes = sizeof(double) * (size_t)ctx->n_gen_rows;
+        TRY(dalloc(ctx, &ctx->d_gen_dx, (size_t)ctx->n_gen_rows)); TRY(dalloc(ctx, &ctx->d_gen_q, (size_t)ctx->n_gen_rows));
+        HIPCHK(hipMemset(ctx->d_gen_dx, 0, bytes)); HIPCHK(hipMemset(ctx->d_gen_q, 0, bytes));
+        if (!ctx->h_gen_dx) {
+            HIPCHK(hipHostMalloc((void **)&ctx->h_gen_dx, bytes)); HIPCHK(hipHostMalloc((void **)&ctx->h_gen_u, bytes));
+            HIPCHK(hipHostMalloc((void **)&ctx->h_gen_z, bytes)); HIPCHK(hipHostMalloc((void **)&ctx->h_gen_q, bytes));
+            HIPCHK(hipEventCreateWithFlags(&ctx->gen_ev, hipEventDisableTiming));
+        }
+        std::memset(ctx->h_gen_dx, 0, bytes); std::memset(ctx->h_gen_u, 0, bytes); std::memset(ctx->h_gen_z, 0, bytes); std::memset(ctx->h_gen_q, 0, bytes);
+    }
     // collision shapes and the general explicit forces (index lists in factor order)
     TRY(dalloc(ctx, &ctx->d_shapes, 1));
     HIPCHK(hipMemcpy(ctx->d_shapes, &ctx->shapes, sizeof(admm_dev::ShapeTable), hipMemcpyHostToDevice));
@@ -610,7 +774,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
     for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
         const Batch &b = ctx->batches[bi];
         if (only_batch >= 0 && (int)bi != only_batch) continue;
-        if (b.n_local == 0) continue;
+        if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;     // user-defined forces: generic_begin / generic_finish
         const BatchDev d = batch_dev(ctx, b);
         const dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
         const double *x = ctx->d_xcur;
@@ -635,6 +799,33 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
         default: return fail(ctx, ADMM_ERR_UNSUPPORTED, "no kernel for kind %d", b.kind);
         }
     }
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+
+// user-defined forces, first half: D_i x of the generic rows -> pinned host memory (asynchronous; the built-in kernels are
+// launched behind it and run while the host projects)
+int generic_begin(admm_hip_ctx *ctx, const double *x) {
+    if (!ctx->n_gen_rows) return ADMM_OK;
+    for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC && b.g_lrows)
+        hipLaunchKernelGGL(admm_dev::generic_dx_kernel, dim3((b.g_lrows + 255) / 256), dim3(256), 0, ctx->stream, b.g_lrows, (const int *)b.d_g_lrow, (const int *)b.d_g_rptr,
+                           (const int *)b.d_g_col, (const double *)b.d_g_val, x, ctx->d_gen_dx);
+    HIPCHK(hipMemcpyAsync(ctx->h_gen_dx, ctx->d_gen_dx, sizeof(double) * (size_t)ctx->n_gen_rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->gen_ev, ctx->stream));
+    return ADMM_OK;
+}
+// second half: wait for the rows, run the caller's project() (Force::project for every user force, System.cpp:57-58),
+// send z - u back and add the elements' shares of dt^2 D^T W^2 (z - u) to the per-node slots
+int generic_finish(admm_hip_ctx *ctx) {
+    if (!ctx->n_gen_rows) return ADMM_OK;
+    HIPCHK(hipEventSynchronize(ctx->gen_ev));
+    if (!ctx->project_hook) return fail(ctx, ADMM_ERR_STATE, "generic batches present but no project hook installed (admm_hip_set_project_hook)");
+    if (ctx->project_hook(ctx->project_user, ctx->dt, ctx->n_gen_rows, ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z) != 0) return fail(ctx, ADMM_ERR_ARG, "project hook failed");
+    for (int64_t r = 0; r < ctx->n_gen_rows; ++r) ctx->h_gen_q[r] = ctx->h_gen_z[r] - ctx->h_gen_u[r];
+    HIPCHK(hipMemcpyAsync(ctx->d_gen_q, ctx->h_gen_q, sizeof(double) * (size_t)ctx->n_gen_rows, hipMemcpyHostToDevice, ctx->stream));
+    for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC && b.g_lslots)
+        hipLaunchKernelGGL(admm_dev::generic_rhs_kernel, dim3((3 * b.g_lslots + 255) / 256), dim3(256), 0, ctx->stream, 3 * b.g_lslots, (const int *)b.d_g_sptr, (const int *)b.d_g_srow,
+                           (const double *)b.d_g_scoef, (const int *)b.d_g_sdst, (const double *)ctx->d_gen_q, ctx->d_fslot);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -690,8 +881,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
         if (n > 0) {
             hipLaunchKernelGGL(shard_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
                                (const int *)ctx->d_comm_slots, (const unsigned char *)ctx->d_comm_mine, (const double *)ctx->d_y, (const double *)ctx->d_c, ctx->d_comm_buf);
-            if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
-            if (ctx->allreduce(ctx->allreduce_user, ctx->d_comm_buf, 3 * (int64_t)n, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+            TRY(do_allreduce(ctx, ctx->d_comm_buf, 3 * (int64_t)n));
             hipLaunchKernelGGL(shard_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
                                (const int *)ctx->d_comm_slots, (const double *)ctx->d_comm_buf, ctx->d_y, ctx->d_c);
         }
@@ -710,8 +900,7 @@ int shard_sync_x(admm_hip_ctx *ctx) {
     if (ctx->levels_top.empty()) return ADMM_OK;
     const int n3 = 3 * ctx->n_nodes;
     hipLaunchKernelGGL(admm_dev::shard_mask_nodes_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const unsigned char *)ctx->d_keep_mask, ctx->d_xcur);
-    if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
-    if (ctx->allreduce(ctx->allreduce_user, ctx->d_xcur, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+    TRY(do_allreduce(ctx, ctx->d_xcur, (int64_t)n3));
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -719,6 +908,7 @@ int shard_sync_x(admm_hip_ctx *ctx) {
 
 // ---- residual tracking (opt-in): buffers are created on first use -------------------------------------
 int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
+    if (ctx->n_gen_rows) return fail(ctx, ADMM_ERR_UNSUPPORTED, "residual tracking is not available with user-defined forces (their u and z live on the host)");
     if (ctx->res_ready && iters <= ctx->res_cap) return ADMM_OK;
     HIPCHK(hipSetDevice(ctx->device_id));
     if (!ctx->res_ready) {
@@ -772,9 +962,8 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
     hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
     if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
-        if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
-        if (ctx->allreduce(ctx->allreduce_user, ctx->d_res_s, (int64_t)n3, (void *)ctx->stream) != 0 || ctx->allreduce(ctx->allreduce_user, r2, 1, (void *)ctx->stream) != 0)
-            return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+        TRY(do_allreduce(ctx, ctx->d_res_s, (int64_t)n3));
+        TRY(do_allreduce(ctx, r2, 1));
     }
     const int nb = (n3 + RES_BLOCK - 1) / RES_BLOCK;
     hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, n3, ctx->d_res_s, ctx->d_res_partial);
@@ -817,6 +1006,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     const char *ls = getenv("ADMM_HIP_LEAF");
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
     if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_GRAPH_COMM")) ctx->graph_comm = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_DENSE_MAX")) ctx->dense_max = atoi(g);
     if (const char *g = getenv("ADMM_HIP_ROOT_INVERSE")) ctx->root_inverse = atoi(g) != 0;
     *out = ctx;
@@ -830,6 +1020,9 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         (void)hipDeviceSynchronize();
         free_device(ctx);
         for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
+        if (ctx->rccl_comm && ctx->rccl_owned) { RcclApi *R = rccl_api(nullptr); if (R) (void)R->CommDestroy(ctx->rccl_comm); }
+        for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
+        if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -882,6 +1075,49 @@ int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *
     }
     ctx->batches.push_back(std::move(b));
     if (batch) *batch = (int)ctx->batches.size() - 1;
+    return ADMM_OK;
+}
+
+int admm_hip_add_generic_batch(admm_hip_ctx *ctx, int n_elems, const int32_t *elem_row_ptr, int64_t n_triplets, const int32_t *trip_row, const int32_t *trip_col,
+                               const double *trip_val, const double *row_weight, int *batch) {
+    if (!ctx || n_elems < 0 || n_triplets < 0 || !elem_row_ptr || (n_triplets && (!trip_row || !trip_col || !trip_val))) return ADMM_ERR_ARG;
+    if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "forces cannot be added after finalize");
+    Batch b; b.kind = ADMM_KIND_GENERIC; b.n_total = n_elems;
+    b.g_elem_row.assign(elem_row_ptr, elem_row_ptr + n_elems + 1);
+    if (b.g_elem_row[0] != 0) return fail(ctx, ADMM_ERR_ARG, "generic batch: elem_row_ptr[0] must be 0");
+    for (int e = 0; e < n_elems; ++e) if (b.g_elem_row[e + 1] < b.g_elem_row[e]) return fail(ctx, ADMM_ERR_ARG, "generic batch: elem_row_ptr must not decrease");
+    const int64_t rows = b.g_elem_row[n_elems];
+    if (rows && !row_weight) return ADMM_ERR_ARG;
+    b.g_rows = rows; b.g_row0 = ctx->n_gen_rows;
+    b.g_roww.assign(row_weight, row_weight + rows);
+    // triplets -> CSR: ascending (row, column), duplicates summed in the order given (Eigen's setFromTriplets sums them too)
+    std::vector<int64_t> ord(n_triplets);
+    std::iota(ord.begin(), ord.end(), (int64_t)0);
+    for (int64_t t = 0; t < n_triplets; ++t) if (trip_row[t] < 0 || trip_row[t] >= rows || trip_col[t] < 0) return fail(ctx, ADMM_ERR_ARG, "generic batch: triplet %lld (row %d, col %d) out of range (%lld rows)", (long long)t, trip_row[t], trip_col[t], (long long)rows);
+    std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t c) { return trip_row[a] != trip_row[c] ? trip_row[a] < trip_row[c] : trip_col[a] < trip_col[c]; });
+    b.g_rowptr.assign(rows + 1, 0);
+    for (int64_t q = 0; q < n_triplets; ++q) {
+        const int64_t t = ord[q];
+        if (!b.g_col.empty() && q > 0 && trip_row[ord[q - 1]] == trip_row[t] && b.g_col.back() == trip_col[t]) { b.g_val.back() += trip_val[t]; continue; }
+        b.g_col.push_back(trip_col[t]); b.g_val.push_back(trip_val[t]); b.g_rowptr[trip_row[t] + 1]++;
+    }
+    for (int64_t r = 0; r < rows; ++r) b.g_rowptr[r + 1] += b.g_rowptr[r];
+    b.g_elem_node.assign(1, 0);
+    for (int e = 0; e < n_elems; ++e) {
+        std::vector<int32_t> nd;
+        for (int64_t p = b.g_rowptr[b.g_elem_row[e]]; p < b.g_rowptr[b.g_elem_row[e + 1]]; ++p) nd.push_back(b.g_col[p] / 3);
+        std::sort(nd.begin(), nd.end()); nd.erase(std::unique(nd.begin(), nd.end()), nd.end());
+        b.g_nodes.insert(b.g_nodes.end(), nd.begin(), nd.end());
+        b.g_elem_node.push_back((int64_t)b.g_nodes.size());
+    }
+    ctx->n_gen_rows += rows;
+    ctx->batches.push_back(std::move(b));
+    if (batch) *batch = (int)ctx->batches.size() - 1;
+    return ADMM_OK;
+}
+int admm_hip_set_project_hook(admm_hip_ctx *ctx, admm_hip_project_fn fn, void *user) {
+    if (!ctx) return ADMM_ERR_ARG;
+    ctx->project_hook = fn; ctx->project_user = user;
     return ADMM_OK;
 }
 
@@ -967,6 +1203,49 @@ int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *us
     return ADMM_OK;
 }
 
+int admm_hip_rccl_unique_id(void *id128) {
+    if (!id128) return ADMM_ERR_ARG;
+    std::string why;
+    RcclApi *R = rccl_api(&why);
+    if (!R) { fprintf(stderr, "admm_hip: %s\n", why.c_str()); return ADMM_ERR_COMM; }
+    nccl_uid id;
+    if (R->GetUniqueId(&id) != 0) return ADMM_ERR_COMM;
+    std::memcpy(id128, &id, sizeof id);
+    return ADMM_OK;
+}
+int admm_hip_rccl_init(admm_hip_ctx *ctx, const void *id128, int rank, int world) {
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return ADMM_ERR_ARG;
+    if (ctx->device_id < 0) return fail(ctx, ADMM_ERR_HIP, "host-only context: no RCCL communicator");
+    std::string why;
+    RcclApi *R = rccl_api(&why);
+    if (!R) return fail(ctx, ADMM_ERR_COMM, "%s", why.c_str());
+    HIPCHK(hipSetDevice(ctx->device_id));       // the communicator binds to the calling thread's current device
+    nccl_uid id; std::memcpy(&id, id128, sizeof id);
+    void *comm = nullptr;
+    const int rc = R->CommInitRank(&comm, world, id, rank);
+    if (rc != 0 || !comm) return fail(ctx, ADMM_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device_id, R->GetErrorString ? R->GetErrorString(rc) : "?");
+    if (ctx->rccl_comm && ctx->rccl_owned) (void)R->CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = comm; ctx->rccl_owned = true;
+    return ADMM_OK;
+}
+int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm) {
+    if (!ctx) return ADMM_ERR_ARG;
+    std::string why;
+    RcclApi *R = rccl_api(&why);
+    if (nccl_comm && !R) return fail(ctx, ADMM_ERR_COMM, "%s", why.c_str());
+    if (ctx->rccl_comm && ctx->rccl_owned && R) (void)R->CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nccl_comm; ctx->rccl_owned = false;
+    return ADMM_OK;
+}
+// parity / bring-up hook: sums `count` doubles of a caller-owned DEVICE buffer through the installed communicator or hook
+int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count) {
+    if (!ctx || ctx->device_id < 0 || !dev_buf || count < 0) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    TRY(do_allreduce(ctx, (double *)dev_buf, count));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
 int admm_hip_finalize(admm_hip_ctx *ctx) {
     if (!ctx) return ADMM_ERR_ARG;
     if (ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "already finalized");
@@ -990,7 +1269,8 @@ int admm_hip_set_weights(admm_hip_ctx *ctx, int batch, const double *weights) {
     if (!ctx || batch < 0 || batch >= (int)ctx->batches.size() || !weights) return ADMM_ERR_ARG;
     if (!ctx->finalized) return fail(ctx, ADMM_ERR_STATE, "set_weights before finalize");
     Batch &b = ctx->batches[batch];
-    std::copy(weights, weights + b.n_total, b.weight.begin());
+    if (b.kind == ADMM_KIND_GENERIC) std::copy(weights, weights + b.g_rows, b.g_roww.begin());
+    else std::copy(weights, weights + b.n_total, b.weight.begin());
     return ADMM_OK;
 }
 
@@ -1004,6 +1284,12 @@ int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
         HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
         if (ctx->dense && ctx->d_ainv) HIPCHK(hipMemcpy(ctx->d_ainv, ctx->Ainv.data(), ctx->Ainv.size() * sizeof(double), hipMemcpyHostToDevice));
         for (Batch &b : ctx->batches) {
+            if (b.kind == ADMM_KIND_GENERIC) {
+                std::vector<double> coef(b.g_sval.size());
+                for (size_t i = 0; i < coef.size(); ++i) { const double w = b.g_roww[b.g_srow_b[i]]; coef[i] = b.g_sval[i] * ((ctx->dt * ctx->dt) * (w * w)); }
+                if (!coef.empty()) HIPCHK(hipMemcpy(b.d_g_scoef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+                continue;
+            }
             const int nl = b.n_local;
             std::vector<double> w2h2(std::max(nl, 1)), w2(std::max(nl, 1));
             for (int el = 0; el < nl; ++el) { const double w = b.weight[b.local[el]]; w2[el] = w * w; w2h2[el] = (ctx->dt * ctx->dt) * (w * w); }
@@ -1062,12 +1348,21 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     TRY(mark(ctx));
     const bool track = ctx->res_on || ctx->tol_r > 0.0;
     if (track) TRY(ensure_residual_buffers(ctx, admm_iters));
-    const bool use_graph = ctx->graph_enabled && ctx->world == 1 && !ctx->timing && !track && admm_iters > 0;
+    if (ctx->n_gen_rows) {      // user-defined forces: curr_z = D * m_x before the loop (System.cpp:43)
+        TRY(generic_begin(ctx, ctx->d_x));
+        HIPCHK(hipEventSynchronize(ctx->gen_ev));
+        std::memcpy(ctx->h_gen_z, ctx->h_gen_dx, sizeof(double) * (size_t)ctx->n_gen_rows);
+    }
+    // world > 1: the iteration contains an all-reduce.  A host hook cannot be captured; ncclAllReduce can (RCCL collectives are
+    // stream-ordered device work), so with the communicator inside the library the multi-GPU iteration is one graph launch too.
+    const bool comm_capturable = ctx->world == 1 || (ctx->rccl_comm != nullptr && ctx->graph_comm);
+    const bool use_graph = ctx->graph_enabled && comm_capturable && !ctx->timing && !track && admm_iters > 0 && !ctx->n_gen_rows;
     if (use_graph && !ctx->iter_exec) {   // capture one iteration; every kernel argument is a fixed device address
         // a stream that cannot be captured (caller-supplied, already capturing ...) is not an error: launch eagerly instead
         const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
         int rc = be == hipSuccess ? launch_local(ctx) : ADMM_ERR_HIP;
         if (!rc) rc = launch_rhs(ctx);
+        if (!rc && ctx->world > 1 && ctx->levels_top.empty()) rc = do_allreduce(ctx, ctx->d_y, (int64_t)n3);   // contiguous sharding (subtree: inside launch_solve)
         if (!rc) rc = launch_solve(ctx, nullptr);
         hipGraph_t g = nullptr;
         const hipError_t ce = be == hipSuccess ? hipStreamEndCapture(ctx->stream, &g) : be;
@@ -1082,14 +1377,15 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     for (int it = 0; it < admm_iters; ++it) {
         if (use_graph && ctx->iter_exec) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
         if (track) TRY(residual_snapshot(ctx, it == 0));
+        TRY(generic_begin(ctx, ctx->d_xcur));
         TRY(launch_local(ctx));
+        TRY(generic_finish(ctx));
         TRY(mark(ctx));
         if (track) { TRY(launch_residuals(ctx, it)); ctx->res_n = it + 1; }
         TRY(launch_rhs(ctx));
         TRY(mark(ctx));
         if (ctx->world > 1 && ctx->levels_top.empty()) {     // contiguous sharding: the whole RHS is summed, the solve is replicated
-            if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but no all-reduce hook installed", ctx->world);
-            if (ctx->allreduce(ctx->allreduce_user, ctx->d_y, (int64_t)n3, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+            TRY(do_allreduce(ctx, ctx->d_y, (int64_t)n3));
         }
         TRY(mark(ctx));
         hipEvent_t mid = nullptr;
@@ -1164,6 +1460,50 @@ int admm_hip_set_v(admm_hip_ctx *ctx, const double *v) {
     return set_nodes(ctx, ctx->d_v, v);
 }
 
+// ---- frame boundary of the class API ------------------------------------------------------------------------
+// One DMA per vector straight from / into the caller's memory (pinned with admm_hip_pin_host: full PCIe rate, truly
+// asynchronous), the reordering between the caller's node order and the factor order on the device.
+int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on) {
+    if (!ctx || !p) return ADMM_ERR_ARG;
+    if (ctx->device_id < 0) return ADMM_OK;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    if (on) HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    else HIPCHK(hipHostUnregister(p));
+    return ADMM_OK;
+}
+int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v) {
+    TRY(require_device(ctx));
+    HIPCHK(hipSetDevice(ctx->device_id));
+    const int n3 = 3 * ctx->n_nodes;
+    const size_t bytes = sizeof(double) * (size_t)n3;
+    if (x) {
+        HIPCHK(hipMemcpyAsync(ctx->d_stage, x, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(admm_dev::permute_in_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_stage, ctx->d_x);
+    }
+    if (v) {
+        HIPCHK(hipMemcpyAsync(ctx->d_stage + n3, v, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(admm_dev::permute_in_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)(ctx->d_stage + n3), ctx->d_v);
+    }
+    HIPCHK(hipGetLastError());
+    return ADMM_OK;
+}
+int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v) {
+    TRY(require_device(ctx));
+    HIPCHK(hipSetDevice(ctx->device_id));
+    const int n3 = 3 * ctx->n_nodes;
+    const size_t bytes = sizeof(double) * (size_t)n3;
+    if (x) {
+        hipLaunchKernelGGL(admm_dev::permute_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_x, ctx->d_stage);
+        HIPCHK(hipMemcpyAsync(x, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (v) {
+        hipLaunchKernelGGL(admm_dev::permute_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_v, ctx->d_stage + n3);
+        HIPCHK(hipMemcpyAsync(v, ctx->d_stage + n3, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
 // SoA [rows][n] device -> element-major [n][rows] host
 static int read_soa(admm_hip_ctx *ctx, const double *d, int rows, int n, double *out) {
     if (!out || n == 0) return ADMM_OK;
@@ -1179,6 +1519,14 @@ int admm_hip_read_local(admm_hip_ctx *ctx, int batch, double *u, double *z, doub
     HIPCHK(hipSetDevice(ctx->device_id));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const Batch &b = ctx->batches[batch];
+    if (b.kind == ADMM_KIND_GENERIC) {      // u, z of this rank's user forces, element after element (they live on the host)
+        size_t o = 0;
+        for (int el = 0; el < b.n_local; ++el) for (int64_t r = b.g_elem_row[b.local[el]]; r < b.g_elem_row[b.local[el] + 1]; ++r, ++o) {
+            if (u) u[o] = ctx->h_gen_u[b.g_row0 + r];
+            if (z) z[o] = ctx->h_gen_z[b.g_row0 + r];
+        }
+        return ADMM_OK;
+    }
     const int rows = ADMM_KIND_ROWS[b.kind];
     TRY(read_soa(ctx, b.d_u, rows, b.n_local, u));
     TRY(read_soa(ctx, b.d_z, rows, b.n_local, z));
@@ -1194,6 +1542,11 @@ int admm_hip_write_local(admm_hip_ctx *ctx, int batch, const double *u, const do
     HIPCHK(hipSetDevice(ctx->device_id));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const Batch &b = ctx->batches[batch];
+    if (b.kind == ADMM_KIND_GENERIC) {
+        size_t o = 0;
+        if (u) for (int el = 0; el < b.n_local; ++el) for (int64_t r = b.g_elem_row[b.local[el]]; r < b.g_elem_row[b.local[el] + 1]; ++r, ++o) ctx->h_gen_u[b.g_row0 + r] = u[o];
+        return ADMM_OK;
+    }
     const int rows = ADMM_KIND_ROWS[b.kind], n = b.n_local;
     if (u && n) {
         std::vector<double> tmp((size_t)rows * n);
@@ -1211,6 +1564,7 @@ int admm_hip_write_local(admm_hip_ctx *ctx, int batch, const double *u, const do
 int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *rest, int32_t *global_idx) {
     if (!ctx || !ctx->finalized || batch < 0 || batch >= (int)ctx->batches.size()) return ADMM_ERR_ARG;
     const Batch &b = ctx->batches[batch];
+    if (b.kind == ADMM_KIND_GENERIC) { if (global_idx) std::copy(b.global_idx.begin(), b.global_idx.end(), global_idx); return ADMM_OK; }   // rest data and weights are the caller's
     if (weight) std::copy(b.weight.begin(), b.weight.end(), weight);
     if (rest) std::copy(b.rest.begin(), b.rest.end(), rest);
     if (global_idx) std::copy(b.global_idx.begin(), b.global_idx.end(), global_idx);
@@ -1221,7 +1575,9 @@ int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur) {
     TRY(require_device(ctx));
     if (!x_cur) return ADMM_ERR_ARG;
     TRY(set_nodes(ctx, ctx->d_xcur, x_cur));
+    TRY(generic_begin(ctx, ctx->d_xcur));
     TRY(launch_local(ctx));
+    TRY(generic_finish(ctx));
     TRY(launch_rhs(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ADMM_OK;
@@ -1235,6 +1591,7 @@ int admm_hip_local_step_dx(admm_hip_ctx *ctx, int batch, const double *dx) {
     if (batch < 0 || batch >= (int)ctx->batches.size() || !dx) return ADMM_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device_id));
     Batch &b = ctx->batches[batch];
+    if (b.kind == ADMM_KIND_GENERIC) return fail(ctx, ADMM_ERR_UNSUPPORTED, "local_step_dx: a generic batch's project() is the caller's own code");
     const int rows = ADMM_KIND_ROWS[b.kind], n = b.n_local;
     if (n == 0) return ADMM_OK;
     std::vector<double> tmp((size_t)rows * n);

@@ -105,6 +105,21 @@ __global__ void epilogue_kernel(int ndof, double dt, double *__restrict__ x, dou
     x[i] = xc;
 }
 
+// Frame boundary of the class API (admm_hip_upload_state / admm_hip_download_state): the caller's node order <-> factor
+// order, on the device, so that the host only ever sees one DMA per vector.  perm[i] = caller's node at factor position i.
+__global__ void permute_in_kernel(int n_nodes, const int *__restrict__ perm, const double *__restrict__ src_caller, double *__restrict__ dst_factor) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_nodes) return;
+    const int node = i / 3, c = i - 3 * node;
+    dst_factor[i] = src_caller[3 * (size_t)perm[node] + c];
+}
+__global__ void permute_out_kernel(int n_nodes, const int *__restrict__ perm, const double *__restrict__ src_factor, double *__restrict__ dst_caller) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n_nodes) return;
+    const int node = i / 3, c = i - 3 * node;
+    dst_caller[3 * (size_t)perm[node] + c] = src_factor[i];
+}
+
 // One lane per dof: b = base + sum of the node's incident per-corner
 // contributions.  The local kernels write every corner's 24 bytes straight to
 // its slot (layouts: admm_hip.hip upload_all), summed here in fixed (batch, element, corner) order.

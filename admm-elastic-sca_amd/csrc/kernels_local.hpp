@@ -422,4 +422,29 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
         for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)b.dst[4 * (size_t)e + c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
 }
 
+// ---------------------------------------------------------------------------
+// User-defined forces (admm_hip_add_generic_batch): the device's share is the two sparse products around the host hook.
+// generic_dx_kernel: Dx = D x for this rank's generic rows, one lane per row, entries in ascending column order from 0.0 --
+// the order of Eigen's column-major product at System.cpp:54.  generic_rhs_kernel: one lane per (node slot, component):
+// sum of coef * (z - u) over the element's rows that touch this node's component, ascending rows (System.cpp:61).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void generic_dx_kernel(int n_rows, const int *__restrict__ lrow, const int *__restrict__ rptr, const int *__restrict__ col,
+                                                         const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ dx) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    double acc = 0.0;
+    for (int k = rptr[r]; k < rptr[r + 1]; ++k) acc += val[k] * x[col[k]];
+    dx[lrow[r]] = acc;
+}
+__global__ __launch_bounds__(256) void generic_rhs_kernel(int n_slotcomps, const int *__restrict__ sptr, const int *__restrict__ srow, const double *__restrict__ scoef,
+                                                          const int *__restrict__ sdst, const double *__restrict__ q, double *__restrict__ fslot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_slotcomps) return;
+    int k = sptr[i];
+    const int e = sptr[i + 1];
+    double acc = 0.0;
+    if (k < e) { acc = scoef[k] * q[srow[k]]; for (++k; k < e; ++k) acc += scoef[k] * q[srow[k]]; }
+    fslot[3 * (size_t)sdst[i / 3] + i % 3] = acc;
+}
+
 } // namespace admm_dev

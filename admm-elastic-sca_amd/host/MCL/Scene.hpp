@@ -48,6 +48,11 @@ template <int D, class T> struct Vec {
     const T &operator[](int i) const { return v[i]; }
     typedef T value_type;
 };
+// trimesh2 Vec.h: component-wise difference / sum, len2 accumulated front to back in T, len = sqrt(len2)
+template <int D, class T> inline Vec<D, T> operator-(const Vec<D, T> &a, const Vec<D, T> &b) { Vec<D, T> r; for (int i = 0; i < D; ++i) r[i] = a[i] - b[i]; return r; }
+template <int D, class T> inline Vec<D, T> operator+(const Vec<D, T> &a, const Vec<D, T> &b) { Vec<D, T> r; for (int i = 0; i < D; ++i) r[i] = a[i] + b[i]; return r; }
+template <int D, class T> inline T len2(const Vec<D, T> &v) { T l2 = v[0] * v[0]; for (int i = 1; i < D; ++i) l2 += v[i] * v[i]; return l2; }
+template <int D, class T> inline T len(const Vec<D, T> &v) { return std::sqrt(len2(v)); }
 typedef Vec<3, float> vec;
 typedef Vec<3, float> point;
 typedef Vec<3, float> vec3;

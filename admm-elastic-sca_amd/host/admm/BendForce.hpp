@@ -1,0 +1,5 @@
+// BendForce.hpp -- forwarding header: the reference keeps BendForce in
+// deps/admm-elastic-sca/src/system/BendForce.hpp; callers include it by that name
+// (src/ForceBuilder.hpp:23-26, samples/*.cpp).  The mirror declares every force class in Force.hpp.
+#pragma once
+#include "Force.hpp"

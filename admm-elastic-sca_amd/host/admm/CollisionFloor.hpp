@@ -1,0 +1,5 @@
+// CollisionFloor.hpp -- forwarding header: the reference keeps CollisionFloor in
+// deps/admm-elastic-sca/src/collision/CollisionFloor.hpp; callers include it by that name
+// (src/ForceBuilder.hpp:23-26, samples/*.cpp).  The mirror declares every force class in Force.hpp.
+#pragma once
+#include "Force.hpp"

@@ -1,0 +1,5 @@
+// CollisionForce.hpp -- forwarding header: the reference keeps CollisionForce in
+// deps/admm-elastic-sca/src/system/CollisionForce.hpp; callers include it by that name
+// (src/ForceBuilder.hpp:23-26, samples/*.cpp).  The mirror declares every force class in Force.hpp.
+#pragma once
+#include "Force.hpp"

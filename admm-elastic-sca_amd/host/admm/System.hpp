@@ -6,10 +6,19 @@
 //   recompute_weights, pre_step_callbacks.
 // initialize() hands nodes and forces to the library (batches of consecutive
 // forces of one kind, in forces[] order), step() runs one frame on the GPU and
-// leaves m_x / m_v valid on return, like the reference.  There is no CPU path:
-// without a GPU initialize() prints the library's error and returns false.
+// leaves m_x / m_v valid on return, like the reference.  There is no CPU path
+// for the built-in forces: without a GPU initialize() prints the library's error
+// and returns false.
+//
+// User-written plug-ins keep working (the reference's extension story,
+// Force.hpp:37-57 and samples/singletet.cpp:100-102): a Force subclass is asked
+// for its selector rows once (get_selector, System.cpp:121-124); every ADMM
+// iteration the device evaluates D_i x for those rows, project() runs here on the
+// host (System.cpp:57-58) and z - u returns to the device-side right-hand side.
+// A user-written ExplicitForce::project runs here at the start of step().
 #pragma once
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <iostream>
 #include <memory>
@@ -24,8 +33,8 @@ namespace admm {
 
 class System {
 public:
-    System() : elapsed_s(0.0), device_id(0), initialized(false), gpu(nullptr) {}
-    ~System() { if (gpu) admm_hip_destroy(gpu); }
+    System() : elapsed_s(0.0), device_id(0), initialized(false), gpu(nullptr), user_rows(0), pinned_x(nullptr), pinned_v(nullptr), seen_x(nullptr), seen_v(nullptr), pinned_bytes(0) {}
+    ~System() { release(); }
     System(const System &) = delete;
     System &operator=(const System &) = delete;
 
@@ -81,15 +90,47 @@ public:
         if (!(m_masses.size() == m_x.size() && m_x.size() >= 3)) { std::cerr << "\n**Solver Error: Problem with node data!" << std::endl; return false; }
         if (m_v.size() < m_x.size()) m_v.resize(m_x.size());
         m_v.setZero();
-        if (gpu) { admm_hip_destroy(gpu); gpu = nullptr; }
-        if (admm_hip_create(&gpu, device_id) != ADMM_OK) { std::cerr << "\n**Solver Error: no usable HIP device " << device_id << " (this solver has no CPU path)" << std::endl; gpu = nullptr; return false; }
+        release();
+        if (admm_hip_create(&gpu, device_id) != ADMM_OK) { std::cerr << "\n**Solver Error: no usable HIP device " << device_id << " (the built-in forces have no CPU path)" << std::endl; gpu = nullptr; return false; }
         if (!check(admm_hip_set_timestep(gpu, settings.timestep_s))) return false;
         if (!check(admm_hip_add_nodes(gpu, dof / 3, m_x.data(), m_masses.data(), nullptr))) return false;
+        // Force::initialize of the user-written forces (System.cpp:117-119); the built-in ones compute their rest data in the library
+        for (size_t i = 0; i < forces.size(); ++i) {
+            Force &f = *forces[i];
+            if (f.kind() >= 0 && typeid(f) != f.device_type()) {
+                std::cerr << "\n**Solver Error: force " << i << " derives from a built-in force class; a subclass must override kind() to return -1 and bring its own get_selector()/project()" << std::endl;
+                return false;
+            }
+            if (f.kind() < 0) f.initialize(m_x, m_v, m_masses, settings.timestep_s);
+        }
         // consecutive forces of one kind (and one anchor flavour) -> one batch, order preserved
-        batch_first.clear(); batch_count.clear(); batch_kind.clear(); batch_moving.clear();
+        batch_first.clear(); batch_count.clear(); batch_kind.clear(); batch_moving.clear(); batch_urow0.clear();
+        user_rows = 0;
+        std::vector<double> user_weights;
         for (size_t i = 0; i < forces.size();) {
             const int kind = forces[i]->kind();
-            if (kind < 0) { std::cerr << "\n**Solver Error: force " << i << " is a user-defined Force subclass; only the built-in kinds have GPU kernels" << std::endl; return false; }
+            if (kind < 0) {      // a run of user-written forces -> one generic batch
+                std::vector<Eigen::Triplet<double> > trips;
+                const size_t row0 = user_weights.size();
+                std::vector<int32_t> erp(1, 0);
+                size_t j = i;
+                for (; j < forces.size() && forces[j]->kind() < 0; ++j) {
+                    const size_t w0 = user_weights.size(), t0 = trips.size();
+                    forces[j]->get_selector(m_x, trips, user_weights);
+                    for (size_t t = t0; t < trips.size(); ++t) if (trips[t].row() < (long)w0 || trips[t].row() >= (long)user_weights.size() || trips[t].col() < 0 || trips[t].col() >= dof) {
+                        std::cerr << "\n**Solver Error: force " << j << " pushed a selector triplet (row " << trips[t].row() << ", col " << trips[t].col() << ") outside the rows [" << w0 << ", " << user_weights.size() << ") it announced through weights" << std::endl;
+                        return false;
+                    }
+                    erp.push_back((int32_t)(user_weights.size() - row0));
+                }
+                std::vector<int32_t> tr(trips.size()), tc(trips.size()); std::vector<double> tv(trips.size());
+                for (size_t t = 0; t < trips.size(); ++t) { tr[t] = (int32_t)(trips[t].row() - (long)row0); tc[t] = (int32_t)trips[t].col(); tv[t] = trips[t].value(); }
+                int b = -1;
+                if (!check(admm_hip_add_generic_batch(gpu, (int)(j - i), erp.data(), (int64_t)trips.size(), tr.data(), tc.data(), tv.data(), user_weights.data() + row0, &b))) return false;
+                batch_first.push_back((int)i); batch_count.push_back((int)(j - i)); batch_kind.push_back(ADMM_KIND_GENERIC); batch_moving.push_back(false); batch_urow0.push_back((long)row0);
+                i = j;
+                continue;
+            }
             if (kind == ADMM_KIND_COLLISION) {           // one force over all nodes -> one element per node
                 CollisionForce *cf = static_cast<CollisionForce *>(forces[i].get());
                 const int nn_ = dof / 3;
@@ -99,7 +140,7 @@ public:
                 if (!check(admm_hip_add_batch(gpu, kind, nn_, idx.data(), par.data(), nullptr, &b))) return false;
                 cf->n_nodes = nn_; cf->Di_rows = dof;
                 if (!push_shapes(cf)) return false;
-                batch_first.push_back((int)i); batch_count.push_back(1); batch_kind.push_back(kind); batch_moving.push_back(false);
+                batch_first.push_back((int)i); batch_count.push_back(1); batch_kind.push_back(kind); batch_moving.push_back(false); batch_urow0.push_back(-1);
                 ++i;
                 continue;
             }
@@ -115,32 +156,42 @@ public:
             }
             int b = -1;
             if (!check(admm_hip_add_batch(gpu, kind, (int)(j - i), idx.data(), par.data(), moving ? tgt.data() : nullptr, &b))) return false;
-            batch_first.push_back((int)i); batch_count.push_back((int)(j - i)); batch_kind.push_back(kind); batch_moving.push_back(moving);
+            batch_first.push_back((int)i); batch_count.push_back((int)(j - i)); batch_kind.push_back(kind); batch_moving.push_back(moving); batch_urow0.push_back(-1);
             i = j;
         }
+        user_rows = (long)user_weights.size();
+        if (user_rows && !check(admm_hip_set_project_hook(gpu, &System::project_hook, this))) return false;
+        // ExplicitForce / WindForce run on the device; a user-written subclass stays on the host (step())
+        explicit_slot.assign(explicit_forces.size(), -1);
         for (size_t i = 0; i < explicit_forces.size(); ++i) {
             const ExplicitForce &ef = *explicit_forces[i];
+            if (!ef.on_device()) continue;
             const double d[3] = {ef.direction[0], ef.direction[1], ef.direction[2]};
             const std::vector<int> &il = ef.index_list();
             const int type = ef.explicit_type();
             const int cnt = (int)il.size() / (type == ADMM_EXPLICIT_WIND ? 3 : 1);
             std::vector<int32_t> il32(il.begin(), il.end());
-            if (!check(admm_hip_add_explicit(gpu, type, d, cnt, il32.empty() ? nullptr : il32.data(), nullptr))) return false;
+            if (!check(admm_hip_add_explicit(gpu, type, d, cnt, il32.empty() ? nullptr : il32.data(), &explicit_slot[i]))) return false;
         }
         if (!check(admm_hip_finalize(gpu))) return false;
         // write back what Force::initialize / get_selector compute in the reference
+        user_local.clear();
         for (size_t b = 0; b < batch_first.size(); ++b) {
-            const int ne = batch_kind[b] == ADMM_KIND_COLLISION ? dof / 3 : batch_count[b];
-            std::vector<double> w(ne), rest((size_t)ne * 12); std::vector<int32_t> g(ne);
-            if (batch_kind[b] == ADMM_KIND_COLLISION) {
-                if (!check(admm_hip_read_rest(gpu, (int)b, w.data(), rest.data(), g.data()))) return false;
-                forces[batch_first[b]]->global_idx = g[0];
+            if (batch_kind[b] == ADMM_KIND_GENERIC) {    // this rank's user forces (all of them on one GPU)
+                int nl = 0;
+                if (!check(admm_hip_local_elements(gpu, (int)b, nullptr, 0, &nl))) return false;
+                std::vector<int32_t> ids(nl > 0 ? nl : 1);
+                if (!check(admm_hip_local_elements(gpu, (int)b, ids.data(), nl, &nl))) return false;
+                for (int q = 0; q < nl; ++q) user_local.push_back(batch_first[b] + ids[q]);
                 continue;
             }
+            const int ne = batch_kind[b] == ADMM_KIND_COLLISION ? dof / 3 : batch_count[b];
+            std::vector<double> w(ne), rest((size_t)ne * 12); std::vector<int32_t> g(ne);
             if (!check(admm_hip_read_rest(gpu, (int)b, w.data(), rest.data(), g.data()))) return false;
-            if (batch_kind[b] == ADMM_KIND_COLLISION) continue;   // weight stays use_weight; rows start at the batch's first element
+            if (batch_kind[b] == ADMM_KIND_COLLISION) { forces[batch_first[b]]->global_idx = g[0]; continue; }   // weight stays use_weight
             for (int e = 0; e < batch_count[b]; ++e) { Force *f = forces[batch_first[b] + e].get(); f->weight = w[e]; f->global_idx = g[e]; }
         }
+        user_Dx.resize(user_rows); user_u.resize(user_rows); user_z.resize(user_rows);
         if (settings.verbose >= 1) std::cout << m_x.size() / 3 << " nodes, " << forces.size() << " forces" << std::endl;
         initialized = true;
         return true;
@@ -160,15 +211,26 @@ public:
             }
             if (!check(admm_hip_update_anchors(gpu, (int)b, tgt.data(), act.data()))) return false;
         }
-        for (size_t i = 0; i < explicit_forces.size(); ++i) { const Vector3d &d = explicit_forces[i]->direction; if (!check(admm_hip_set_gravity(gpu, (int)i, d[0], d[1], d[2]))) return false; }
+        // user-written explicit forces act on the host copy before it is uploaded (System.cpp:37-39; they run before the
+        // device-side ones, in their own relative order)
+        for (size_t i = 0; i < explicit_forces.size(); ++i) {
+            if (explicit_slot[i] < 0) { explicit_forces[i]->project(settings.timestep_s, m_x, m_v, m_masses); continue; }
+            const Vector3d &d = explicit_forces[i]->direction;
+            if (!check(admm_hip_set_gravity(gpu, explicit_slot[i], d[0], d[1], d[2]))) return false;
+        }
         for (size_t b = 0; b < batch_first.size(); ++b) if (batch_kind[b] == ADMM_KIND_COLLISION && !push_shapes(static_cast<CollisionForce *>(forces[batch_first[b]].get()))) return false;
-        // m_x / m_v are public and may have been edited by the caller between steps
-        if (!check(admm_hip_set_x(gpu, m_x.data())) || !check(admm_hip_set_v(gpu, m_v.data()))) return false;
+        // m_x / m_v are public and may have been edited by the caller between steps: they travel every frame, one DMA each
+        // way per vector out of / into the vectors' own (page-locked) memory
+        pin_state();
+        if (!check(admm_hip_upload_state(gpu, m_x.data(), m_v.data()))) return false;
         if (!check(admm_hip_set_tolerance(gpu, settings.residual_tol_primal, settings.residual_tol_dual, settings.residual_check_every < 1 ? 1 : settings.residual_check_every))) return false;
         if (!check(admm_hip_step(gpu, settings.admm_iters))) return false;
-        if (!check(admm_hip_get_x(gpu, m_x.data())) || !check(admm_hip_get_v(gpu, m_v.data()))) return false;
+        if (!check(admm_hip_download_state(gpu, m_x.data(), m_v.data()))) return false;
         // released MovingAnchors follow their node: point->pos = Dx (AnchorForce.cpp:80-83)
         for (size_t b = 0; b < batch_first.size(); ++b) if (batch_moving[b]) {
+            bool any_released = false;
+            for (int e = 0; e < batch_count[b] && !any_released; ++e) any_released = !static_cast<MovingAnchor *>(forces[batch_first[b] + e].get())->point->active;
+            if (!any_released) continue;
             std::vector<double> tgt((size_t)batch_count[b] * 3);
             if (!check(admm_hip_read_local(gpu, (int)b, nullptr, nullptr, tgt.data(), nullptr))) return false;
             for (int e = 0; e < batch_count[b]; ++e) {
@@ -183,7 +245,15 @@ public:
     // System.cpp:159-179: Force::weight was edited by the caller
     void recompute_weights() {
         if (!initialized) return;
+        // user forces announce their weights through get_selector again (System.cpp:165-168); same call order -> same global_idx
+        std::vector<Eigen::Triplet<double> > trips; std::vector<double> user_weights;
+        for (size_t i = 0; i < forces.size(); ++i) if (forces[i]->kind() < 0) forces[i]->get_selector(m_x, trips, user_weights);
+        if ((long)user_weights.size() != user_rows) { std::cerr << "\n**Solver Error: user forces changed their row count in recompute_weights" << std::endl; return; }
         for (size_t b = 0; b < batch_first.size(); ++b) {
+            if (batch_kind[b] == ADMM_KIND_GENERIC) {
+                if (!check(admm_hip_set_weights(gpu, (int)b, user_weights.data() + batch_urow0[b]))) return;
+                continue;
+            }
             const int ne = batch_kind[b] == ADMM_KIND_COLLISION ? (int)m_x.size() / 3 : batch_count[b];
             std::vector<double> w(ne);
             for (int e = 0; e < ne; ++e) w[e] = forces[batch_first[b] + (batch_kind[b] == ADMM_KIND_COLLISION ? 0 : e)]->weight;
@@ -199,6 +269,46 @@ protected:
     admm_hip_ctx *gpu;
     std::vector<int> batch_first, batch_count, batch_kind;
     std::vector<char> batch_moving;
+    std::vector<long> batch_urow0;         // generic batches: first of their rows among the user rows (-1 otherwise)
+    std::vector<int> explicit_slot;        // explicit_forces[i] -> index among the device-side explicit forces, -1 = host
+    // user-written forces: their rows of Dx / u / z (the vectors Force::project receives) and this rank's forces
+    long user_rows;
+    std::vector<int> user_local;
+    VectorXd user_Dx, user_u, user_z;
+    void *pinned_x, *pinned_v, *seen_x, *seen_v; size_t pinned_bytes;
+
+    // Force::project for every user force of this rank (System.cpp:57-58), on the rows the library hands over
+    static int project_hook(void *self_, double dt, int64_t n_rows, const double *Dx, double *u, double *z) {
+        System *self = static_cast<System *>(self_);
+        if (n_rows != (int64_t)self->user_rows) return 1;
+        const size_t bytes = sizeof(double) * (size_t)n_rows;
+        std::memcpy(self->user_Dx.data(), Dx, bytes); std::memcpy(self->user_u.data(), u, bytes); std::memcpy(self->user_z.data(), z, bytes);
+        const int nf = (int)self->user_local.size();
+#pragma omp parallel for
+        for (int i = 0; i < nf; ++i) self->forces[self->user_local[i]]->project(dt, self->user_Dx, self->user_u, self->user_z);
+        std::memcpy(u, self->user_u.data(), bytes); std::memcpy(z, self->user_z.data(), bytes);
+        return 0;
+    }
+
+    // page-lock m_x / m_v where they lie (again if the caller resized them)
+    void pin_state() {
+        const size_t bytes = sizeof(double) * (size_t)m_x.size();
+        if (seen_x == (void *)m_x.data() && seen_v == (void *)m_v.data() && pinned_bytes == bytes) return;
+        unpin_state();
+        seen_x = m_x.data(); seen_v = m_v.data(); pinned_bytes = bytes;       // tried once per buffer: pageable memory still works, just slower
+        if (admm_hip_pin_host(gpu, m_x.data(), bytes, 1) == ADMM_OK) pinned_x = m_x.data();
+        if (admm_hip_pin_host(gpu, m_v.data(), bytes, 1) == ADMM_OK) pinned_v = m_v.data();
+    }
+    void unpin_state() {
+        if (gpu && pinned_x) admm_hip_pin_host(gpu, pinned_x, pinned_bytes, 0);
+        if (gpu && pinned_v) admm_hip_pin_host(gpu, pinned_v, pinned_bytes, 0);
+        pinned_x = pinned_v = seen_x = seen_v = nullptr; pinned_bytes = 0;
+    }
+    void release() {
+        unpin_state();
+        if (gpu) { admm_hip_destroy(gpu); gpu = nullptr; }
+        initialized = false;
+    }
 
     bool push_shapes(const CollisionForce *cf) {
         std::vector<int32_t> ty; std::vector<double> par;

@@ -17,6 +17,7 @@
 #ifndef ADMM_HIP_H
 #define ADMM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "admm_kinds.h"
 
@@ -72,6 +73,32 @@ int admm_hip_add_nodes(admm_hip_ctx *ctx, int n_nodes, const double *x, const do
 int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *idx,
                        const double *params, const double *targets, int *batch);
 
+/* ---- user-defined forces ----------------------------------------------------
+ * replaces: system->forces.push_back(new <user subclass of admm::Force>): the reference's extension
+ * story is "subclass admm::Force, implement get_selector + project, push it into system->forces"
+ * (Force.hpp:37-57; documented at samples/singletet.cpp:100-102; System.cpp:121-124 collects the
+ * selector triplets and weights, System.cpp:57-58 calls project once per ADMM iteration).
+ * A generic batch is a run of consecutive user forces ("elements"): element e owns the batch rows
+ * [elem_row_ptr[e], elem_row_ptr[e+1]); its selector rows come as triplets (row relative to the batch,
+ * col = 3*node + component like the reference's D, value), duplicates are summed; row_weight [n_rows]
+ * is what get_selector pushed into `weights`.  The batch takes its place in the order of add_batch
+ * calls.  The library needs  dt^2 D^T W^2 D = K (x) I3  for every element (true whenever a row touches
+ * one coordinate and the x/y/z rows look alike, as for every force of the reference); anything else is
+ * refused at finalize with ADMM_ERR_UNSUPPORTED.
+ * Per ADMM iteration the device evaluates D_i x for the generic rows, the rows travel to the host and
+ * the hook runs the user's project() there -- user code is host code --, then z - u returns to the
+ * device and joins the right-hand side through the same per-node slots as every other force.
+ * The hook mirrors Force::project(dt, Dx, u, z): Dx, u, z cover ALL generic rows of the context
+ * (generic batches concatenated in add order: a force's offset is the `weights.size()` it saw in
+ * get_selector when only user forces push weights); it must update u and z of this rank's elements
+ * (admm_hip_local_elements) and leave the rest alone.  u starts at 0 and persists; z is D*m_x at the
+ * start of every frame (System.cpp:43).  No HIP graph, no residual tracking with generic batches.   */
+typedef int (*admm_hip_project_fn)(void *user, double dt, int64_t n_rows, const double *Dx, double *u, double *z);
+int admm_hip_add_generic_batch(admm_hip_ctx *ctx, int n_elems, const int32_t *elem_row_ptr, int64_t n_triplets,
+                               const int32_t *trip_row, const int32_t *trip_col, const double *trip_val,
+                               const double *row_weight, int *batch);
+int admm_hip_set_project_hook(admm_hip_ctx *ctx, admm_hip_project_fn fn, void *user);
+
 /* replaces: system->explicit_forces.push_back(new ExplicitForce(dir))
  * (ExplicitForce.hpp:51-59, ExplicitForce.cpp:29-39): v += dt*dir on all nodes,
  * once per frame before the ADMM loop.                                       */
@@ -100,6 +127,19 @@ int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t
 typedef int (*admm_hip_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *hip_stream);
 int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world);
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user);
+/* RCCL inside the library (north_star: "host stays C++"): with a communicator installed the per-iteration exchange is
+ * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, <the context's stream>) issued by the step loop itself -- no
+ * host hook between the kernels, and (ADMM_HIP_GRAPH_COMM=1) the whole multi-GPU iteration replays as one HIP graph.
+ * librccl.so is bound at run time with dlopen (the copy already loaded in the process first, e.g. PyTorch's; env
+ * ADMM_HIP_RCCL_LIB overrides); single-GPU users never load it.
+ *   admm_hip_rccl_unique_id  rank 0: 128 bytes (ncclUniqueId) to hand to every rank by whatever means the host has
+ *   admm_hip_rccl_init       every rank, collectively: ncclCommInitRank on the context's device; the library owns the communicator
+ *   admm_hip_set_rccl_comm   use an ncclComm_t the caller already has (not owned; NULL = back to the hook)
+ *   admm_hip_debug_allreduce one checked all-reduce of a caller-owned device buffer through whatever is installed     */
+int admm_hip_rccl_unique_id(void *id128);
+int admm_hip_rccl_init(admm_hip_ctx *ctx, const void *id128, int rank, int world);
+int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm);
+int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count);
 /* How the work is split across the ranks (before finalize; env ADMM_HIP_SHARD=contiguous|subtree overrides):
  *   ADMM_SHARD_CONTIGUOUS  every batch is cut into `world` contiguous element ranges; per ADMM iteration the whole right-hand
  *                          side (3 n doubles) is all-reduced and every rank runs the complete solve.
@@ -126,6 +166,7 @@ int admm_hip_finalize(admm_hip_ctx *ctx);
 
 /* replaces: System::recompute_weights()                   (System.cpp:159-179)
  * after admm_hip_set_weights changed per-element weights: re-assemble, re-factor, re-upload. */
+/* weights: [n_elems] (a generic batch: [n_rows], one per selector row as get_selector pushes them) */
 int admm_hip_set_weights(admm_hip_ctx *ctx, int batch, const double *weights);
 int admm_hip_recompute_weights(admm_hip_ctx *ctx);
 
@@ -151,6 +192,16 @@ int admm_hip_get_x(admm_hip_ctx *ctx, double *x);
 int admm_hip_set_x(admm_hip_ctx *ctx, const double *x);
 int admm_hip_get_v(admm_hip_ctx *ctx, double *v);
 int admm_hip_set_v(admm_hip_ctx *ctx, const double *v);
+
+/* The frame boundary of the class API: what host/admm/System.hpp does around admm_hip_step because m_x / m_v are
+ * public members a caller may read or edit between steps (System.hpp:47-49; samples/singletet.cpp:44 writes m_x).
+ * upload_state is asynchronous on the context's stream (x, v or both; NULL = leave the device copy), download_state
+ * returns when both vectors have arrived.  One DMA per vector straight from / into the caller's memory; the
+ * reordering to the factor's node order runs on the device.  admm_hip_pin_host page-locks (on = 1) or releases
+ * (on = 0) a caller buffer so that these DMAs run at full PCIe rate without a staging copy.                      */
+int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on);
+int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v);
+int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v);
 
 /* ---- parity / introspection ------------------------------------------------
  * u, z: [n_local_elems][rows] element-major (compact rows), state:

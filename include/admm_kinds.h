@@ -43,7 +43,9 @@ enum admm_kind {
     ADMM_KIND_COLLISION  = 8,
     ADMM_KIND_TRI_AREA   = 9,
     ADMM_KIND_TRI_FUNG   = 10,
-    ADMM_KIND_COUNT      = 11
+    ADMM_KIND_COUNT      = 11,  /* built-in kinds (size of the tables below) */
+    ADMM_KIND_GENERIC    = 11   /* a run of user-defined admm::Force subclasses: selector rows given as triplets, project() runs in
+                                   the caller's hook on the host (admm_hip_add_generic_batch); no table entries */
 };
 
 /* nodes per element */

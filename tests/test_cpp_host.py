@@ -23,7 +23,7 @@ def compile_cpp(name, pkg):
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, name)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    cmd = ["g++", "-std=c++11", "-O2", "-DADMM_HOST_NO_EIGEN", "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+    cmd = ["g++", "-std=c++11", "-O2", "-fopenmp", "-DADMM_HOST_NO_EIGEN", "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(PKG, "host", "admm"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            "-L" + PKG, "-ladmm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out
@@ -35,7 +35,7 @@ def have_gpu():
 
 
 def test_compiles_and_fails_loudly_without_gpu(pkg):
-    for name in ("singletet", "singlenode", "scene_bar", "scene_plinko"):
+    for name in ("singletet", "singlenode", "scene_bar", "scene_plinko", "user_force", "dillo_main"):
         exe = compile_cpp(name, pkg)
         assert os.path.exists(exe)
     if have_gpu():
@@ -123,3 +123,122 @@ def test_plinko_scene_through_class_api(pkg, tmp_path):
     X = np.fromfile(outp, dtype=np.float64).reshape(frames, 3 * n)
     for fi, f in enumerate(g["frames"]):
         assert np.abs(X[f] - g["x_frames"][fi]).max() < 1e-9      # the compiled reference's trajectory
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# "existing ForceBuilder + SimContext scenes drop in unchanged" and the plug-in surface (b)
+# ---------------------------------------------------------------------------------------------------------------
+REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+DILLO_XML = os.path.join(ROOT, "tests", "golden", "scenes", "poordillo", "poordillo.xml")
+
+
+def test_reference_callers_compile_and_link_unchanged(pkg):
+    """Build container only: the reference's OWN samples/singletet.cpp, samples/singlenode.cpp, src/SimContext.cpp and
+    src/ForceBuilder.cpp, untouched and from where they lie, compile and LINK against the class mirror host/admm (through
+    the per-class forwarding headers they include) and libadmm_hip.so (oracle/Makefile hip_callers).  Without a GPU the
+    resulting programs get as far as System::initialize() and fail loudly there."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("the reference tree is only present in the build container")
+    pkg.lib()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "hip_callers"])
+    for exe in ("singletet_hip", "singlenode_hip", "dillo_hip"):
+        assert os.path.exists(os.path.join(REF_BIN, exe))
+    if have_gpu():
+        return
+    r = subprocess.run([os.path.join(REF_BIN, "singletet_hip")], capture_output=True, text=True)
+    assert "no usable HIP device" in r.stderr          # singletet.cpp:37 returns 0 when initialize() fails
+    r = subprocess.run([os.path.join(REF_BIN, "dillo_hip"), DILLO_XML, os.devnull, "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Tetmesh dillo has 2761 tets" in r.stdout and "no usable HIP device" in r.stderr
+
+
+def _run_user_force(pkg, tmp_path, mode, g):
+    out = tmp_path / ("uf%d.bin" % mode)
+    r = subprocess.run([compile_cpp("user_force", pkg), str(mode), str(out), str(int(g["frames"])), str(int(g["iters"])), str(int(g["n"]))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    raw = np.fromfile(out, dtype=np.float64)
+    n3 = 3 * int(g["n"]) ** 2
+    nf = int(g["frames"])
+    return raw[:nf * n3].reshape(nf, n3), raw[nf * n3:].reshape(-1, 2)
+
+
+@pytest.mark.gpu
+def test_user_spring_matches_builtin_bit_for_bit(pkg, tmp_path):
+    """A user-written admm::Force subclass doing Spring's arithmetic (tests/cpp/user_force.cpp MySpring; its project() runs
+    on the host, Dx and the right-hand side on the device) against the built-in ADMM_KIND_SPRING kernel: every frame of the
+    trajectory is bitwise the same.  (The real reference agrees with itself the same way: make_golden_user.py asserts it.)"""
+    g = golden("user_force.npz")
+    x0, _ = _run_user_force(pkg, tmp_path, 0, g)
+    x1, gw = _run_user_force(pkg, tmp_path, 1, g)
+    assert np.array_equal(x0, x1)
+    assert np.array_equal(gw, g["gw_mode1"])            # global_idx = 0, 3, 6, ... and weight = sqrt(k), as in the reference
+    assert np.abs(x1 - g["x_mode1"]).max() < 1e-9        # and the compiled reference's trajectory (different elimination order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 3])
+def test_user_plugins_vs_compiled_reference(pkg, tmp_path, mode):
+    """User-written Force (ShellForce), ExplicitForce (SwirlForce) and CollisionShape (SlabShape, which turns its
+    CollisionForce into a host-projected force) -- the same source file compiled with the real reference produced the
+    fixture (tests/golden/make_golden_user.py)."""
+    g = golden("user_force.npz")
+    x, gw = _run_user_force(pkg, tmp_path, mode, g)
+    assert np.abs(x - g["x_mode%d" % mode]).max() < 1e-8
+    assert np.array_equal(gw[:, 1], g["gw_mode%d" % mode][:, 1])        # weights
+
+
+def _check_dillo(out, g, release):
+    hdr = np.fromfile(out, dtype=np.int32, count=3)
+    assert hdr[0] == int(g["dof"]) and hdr[1] == int(g["n_hand"]) and hdr[2] == int(g["n_foot"])     # same grabbed vertices
+    raw = np.fromfile(out, dtype=np.float64, offset=12)
+    nf = int(g["frames"]); dof = int(g["dof"])
+    X = raw[:nf * dof].reshape(nf, dof)
+    assert np.isfinite(X).all()
+    if release < 0:
+        ref, env, frames = g["x_frames"], g["ulp_sensitivity"], range(nf)
+    else:
+        ref, env, frames = g["x_release"], g["ulp_sensitivity_release"], [int(f) for f in g["release_keep"]]
+    # the reference's own resolution: its trajectory moves by `env` when its start moves by 1-3 ulps (truncated L-BFGS +
+    # Armadillo contacts: chaotic from frame 4 on, DESIGN.md 4.6); 20 x that while it is tiny, 5 x once it is macroscopic
+    for k, f in enumerate(frames):
+        e = float(env[k]); bound = 20.0 * e if e < 1e-3 else 5.0 * e
+        err = np.abs(X[f] - ref[k]).max()
+        assert err < max(bound, 1e-9), (f, err, e)
+    if release >= 0:
+        assert np.abs(raw[nf * dof:] - g["hand_cp_after_release"]).max() < 5.0 * float(env[-1])      # a released anchor follows its node
+    else:
+        assert np.abs(X[-1] - X[0]).max() > 1.9              # the grabbers really dragged hand and foot 2 m apart
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("release", [-1, 30])
+def test_poordillo_scripted_grabbers(pkg, tmp_path, release):
+    """BASELINE.json configs[2] as SURVEY 8(d) config 3 specifies it: the shipped armadillo with the sample's MovingAnchors
+    on hand and foot dragged by smooth_move over t in [1, 3] s (and, second case, the hand released at frame 30 through
+    weight = 0 + recompute_weights), loaded from the XML by the headless SimContext, against the compiled reference's
+    trajectory within the reference's own 1-3 ulp sensitivity envelope, frame by frame."""
+    g = golden("traj_dillo_grab.npz")
+    out = tmp_path / "d.bin"
+    r = subprocess.run([compile_cpp("dillo_main", pkg), DILLO_XML, str(out), str(int(g["frames"])), str(release)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    _check_dillo(out, g, release)
+
+
+@pytest.mark.gpu
+def test_reference_programs_run_on_the_gpu(pkg, tmp_path):
+    """The binaries of test_reference_callers_compile_and_link_unchanged travel with the snapshot (oracle/_ref/): the
+    reference's own sample mains and scene layer, running on the MI355X through the mirror.  singletet prints the
+    reference's known answer; the poordillo script through the REFERENCE's SimContext/ForceBuilder matches the fixture."""
+    if not os.path.exists(os.path.join(REF_BIN, "singletet_hip")):
+        pytest.skip("oracle/_ref/*_hip not built (they need the reference tree)")
+    pkg.lib()
+    r = subprocess.run([os.path.join(REF_BIN, "singletet_hip")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Node 4 x: 171.571" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(REF_BIN, "singlenode_hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for want in ("-9.8", "-29.4", "-58.8", "-98"):
+        assert want in r.stdout
+    g = golden("traj_dillo_grab.npz")
+    out = tmp_path / "d.bin"
+    r = subprocess.run([os.path.join(REF_BIN, "dillo_hip"), DILLO_XML, str(out), str(int(g["frames"])), "-1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    _check_dillo(out, g, -1)
