@@ -1191,8 +1191,8 @@ int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
 #ifdef ADMM_TET_PROFILE
 // tools/tet_phase_profile.py only (variant build): read and clear the tet kernel's phase counters
 extern "C" int admm_hip_debug_tet_profile(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 32) != hipSuccess) return ADMM_ERR_HIP;
-    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 96) != hipSuccess) return ADMM_ERR_HIP;
+    unsigned long long zero[96] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_tet_prof), zero, sizeof(zero)) != hipSuccess) return ADMM_ERR_HIP;
     return ADMM_OK;
 }

@@ -33,7 +33,7 @@ namespace admm_dev {
 // ---- phase attribution of the tet kernel (tools/tet_phase_profile.py; build flag -DADMM_TET_PROFILE, never on in the
 // shipped library): s_memtime deltas accumulated by lane 0 of every wave, per-lane loop counts as (sum, 64 x wave maximum)
 #if defined(ADMM_TET_PROFILE) && defined(__HIPCC__)
-__device__ unsigned long long g_tet_prof[32];
+__device__ unsigned long long g_tet_prof[96];   // [0..31] phase ticks / loop counts, [32..63] histogram of line-search evaluations per tet, [64..95] of the wave maxima
 #endif
 #if defined(ADMM_TET_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ unsigned long long prof_now() { return __builtin_readcyclecounter(); }
@@ -49,12 +49,20 @@ __device__ __forceinline__ void prof_count(int idx, int v) {
 }
 #define ADMM_PROF_T0 unsigned long long prof_t = admm_dev::prof_now();
 #define ADMM_PROF_TIME(i) admm_dev::prof_time(i, prof_t)
+__device__ __forceinline__ void prof_hist(int v) {
+    int mx = v;
+    for (int o = 32; o; o >>= 1) { const int other = __shfl_xor(mx, o); mx = other > mx ? other : mx; }
+    atomicAdd(&g_tet_prof[32 + (v < 31 ? v : 31)], 1ull);
+    if (threadIdx.x == 0) atomicAdd(&g_tet_prof[64 + (mx < 31 ? mx : 31)], 1ull);
+}
 #define ADMM_PROF_COUNT(i, v) admm_dev::prof_count(i, v)
+#define ADMM_PROF_HIST(v) admm_dev::prof_hist(v)
 #define ADMM_PROF_ON 1
 #else
 #define ADMM_PROF_T0
 #define ADMM_PROF_TIME(i)
 #define ADMM_PROF_COUNT(i, v)
+#define ADMM_PROF_HIST(v)
 #define ADMM_PROF_ON 0
 #endif
 
@@ -653,7 +661,7 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     sa = x2.a; sb = x2.b; sc = x2.c;
     ADMM_PROF_TIME(2);
 #if ADMM_PROF_ON
-    ADMM_PROF_COUNT(12, n_iters); ADMM_PROF_COUNT(14, P.prof_nfev);
+    ADMM_PROF_COUNT(12, n_iters); ADMM_PROF_COUNT(14, P.prof_nfev); ADMM_PROF_HIST(P.prof_nfev);
     const Mat3 zr = recompose(U, x2.a, x2.b, x2.c, V);
     ADMM_PROF_TIME(3);
     return zr;
