@@ -83,7 +83,8 @@ struct Explicit {
 struct LevelDev {
     int n_small = 0; admm_dev::SweepItem *d_small = nullptr;   // forward: wave items (levels below the split)
     int n_big = 0; admm_dev::SweepItem *d_big = nullptr;       // forward: block items
-    int n_root = 0; admm_dev::SweepItem *d_root = nullptr;     // forward: tiles of roots solved with their explicit inverse (no backward items)
+    struct Root { int k, first; int64_t foff, inv_off; };
+    std::vector<Root> roots;                                   // roots solved with their explicit inverse: gather + one row-wise product (no backward items)
     int n_bwd = 0, bwd_cw = 1; admm_dev::SweepItem *d_bwd = nullptr;
 };
 
@@ -358,7 +359,12 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
         int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
         if (const char *e = getenv("ADMM_HIP_MERGE")) merge_above = atoi(e);
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above);
+        // large systems: only the top region merges (root = top separator + its two half-separators, solved as one dense product
+        // with its explicit inverse): the two top levels of both sweeps -- ~20 us of latency each at 1M tets -- become one
+        // HBM-rate product of k^2 doubles (3335^2 x 8 B = 89 MB at the 1M-tet bar)
+        bool merge_root = merge_above == 0 && ctx->root_inverse;
+        if (const char *e = getenv("ADMM_HIP_MERGE_ROOT")) merge_root = atoi(e) != 0;
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root);
     }
     int err = factorize(ctx->A, ctx->F, threads);
     if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
@@ -515,7 +521,7 @@ int upload_factor(admm_hip_ctx *ctx) {
     for (int pass = 0; pass < (subtree ? 2 : 1); ++pass) {      // pass 0: this rank's supernodes (all of them without subtree sharding), pass 1: the replicated top
         for (size_t l = 0; l < F.levels.size(); ++l) {
             LevelDev &L = pass == 0 ? ctx->levels[l] : ctx->levels_top[l];
-            std::vector<admm_dev::SweepItem> sm, bg, bw, rt;
+            std::vector<admm_dev::SweepItem> sm, bg, bw;
             L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
             for (int s : F.levels[l]) {
                 if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
@@ -526,17 +532,15 @@ int upload_factor(admm_hip_ctx *ctx) {
                 const int f = S.ncols + S.nrows;
                 const int tiles = (f + 63) / 64;
                 if (S.root_inv_off >= 0 && ctx->root_inverse) {      // a root: x = (L L^T)^-1 t in the forward sweep, nothing in the backward sweep
-                    admm_dev::SweepItem ri = it;
-                    ri.panel_off = S.root_inv_off; ri.pad = 1;
-                    for (int t = 0; t < tiles; ++t) { ri.part = t; rt.push_back(ri); }
+                    L.roots.push_back({S.ncols, S.first, S.front_off, S.root_inv_off});
                     continue;
                 }
                 for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
                 const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
                 for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
             }
-            L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size(); L.n_root = (int)rt.size();
-            TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw)); TRY(upload(ctx, &L.d_root, rt));
+            L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
+            TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
         }
     }
     // subtree sharding: the exchange lists (see shard_pack_kernel) and the node masks
@@ -839,7 +843,7 @@ int launch_rhs(admm_hip_ctx *ctx) {
 }
 
 // both triangular sweeps: d_y (rhs, destroyed) -> d_xcur
-int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
+int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hipEvent_t ex1 = nullptr) {
     using namespace admm_dev;
     if (ctx->dense) {   // small system: one kernel, x = A_s^-1 b
         if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
@@ -858,9 +862,11 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
                 if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
                 else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
-            if (L.n_root) {      // roots: both sweeps as one product with the explicit inverse, straight into x
-                if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_root), dim3(1024), 0, ctx->stream, L.d_root, F, ctx->d_y, ctx->d_xcur, ctx->d_c);
-                else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_root), dim3(1024), 0, ctx->stream, L.d_root, F, ctx->d_y, ctx->d_xcur, ctx->d_c);
+            for (const LevelDev::Root &R : L.roots) {      // roots: both sweeps as one product with the explicit inverse, straight into x
+                double *T = ctx->d_w + 3 * (size_t)R.first;      // the root's own slice of W is free: it has no backward launch
+                if (F.cg4) hipLaunchKernelGGL((root_gather_kernel<true>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
+                else hipLaunchKernelGGL((root_gather_kernel<false>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
+                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + 15) / 16), dim3(1024), 0, ctx->stream, R.k, (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
             }
         }
     };
@@ -878,6 +884,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
         // subtree sharding: own subtrees are done; ONE small all-reduce carries the top nodes' partial right-hand sides and the
         // subtree roots' contributions to every rank, then everybody runs the (replicated) top of the tree
         const int n = ctx->n_comm_top + ctx->n_comm_slots;
+        if (ex0) HIPCHK(hipEventRecord(ex0, ctx->stream));
         if (n > 0) {
             hipLaunchKernelGGL(shard_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
                                (const int *)ctx->d_comm_slots, (const unsigned char *)ctx->d_comm_mine, (const double *)ctx->d_y, (const double *)ctx->d_c, ctx->d_comm_buf);
@@ -885,6 +892,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid) {
             hipLaunchKernelGGL(shard_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_comm_top, (const int *)ctx->d_comm_top, ctx->n_comm_slots,
                                (const int *)ctx->d_comm_slots, (const double *)ctx->d_comm_buf, ctx->d_y, ctx->d_c);
         }
+        if (ex1) HIPCHK(hipEventRecord(ex1, ctx->stream));
         forward(ctx->levels_top);
     }
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
@@ -1388,12 +1396,16 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
             TRY(do_allreduce(ctx, ctx->d_y, (int64_t)n3));
         }
         TRY(mark(ctx));
-        hipEvent_t mid = nullptr;
+        // timing mode: one event between the sweeps; under subtree sharding two more around the exchange inside the forward
+        // sweep (pack, all-reduce, unpack), so that allreduce_ms shows the communication and solve_fwd_ms only the sweeps
+        hipEvent_t mid = nullptr, ex0 = nullptr, ex1 = nullptr;
         if (ctx->timing) {
-            if (ctx->ev_used == ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
+            const int want = ctx->levels_top.empty() ? 1 : 3;
+            while (ctx->ev_used + want > ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
+            if (want == 3) { ex0 = ctx->evpool[ctx->ev_used++]; ex1 = ctx->evpool[ctx->ev_used++]; }
             mid = ctx->evpool[ctx->ev_used++];
         }
-        TRY(launch_solve(ctx, mid));
+        TRY(launch_solve(ctx, mid, ex0, ex1));
         TRY(mark(ctx));
         iters_done = it + 1;
         if (ctx->tol_r > 0.0 && (it + 1) % ctx->check_every == 0 && it + 1 < admm_iters) {   // convergence test: one round trip
@@ -1697,19 +1709,27 @@ int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t) {
     if (ctx->ev_pending && ctx->device_id >= 0) {
         HIPCHK(hipSetDevice(ctx->device_id));
         const std::vector<hipEvent_t> &E = ctx->evpool;
-        const size_t need = 3 + 5 * (size_t)ctx->ev_iters;
+        const size_t per = ctx->levels_top.empty() ? 5 : 7;       // events per ADMM iteration (see admm_hip_step)
+        const size_t need = 3 + per * (size_t)ctx->ev_iters;
         if (ctx->ev_used != need) return fail(ctx, ADMM_ERR_STATE, "timing events incomplete (%zu of %zu)", ctx->ev_used, need);
         HIPCHK(hipEventSynchronize(E[need - 1]));
         admm_hip_timing T{};
         float v;
         HIPCHK(hipEventElapsedTime(&v, E[0], E[1])); T.prologue_ms = v;
         for (int it = 0; it < ctx->ev_iters; ++it) {
-            const size_t b = 1 + 5 * (size_t)it;
+            const size_t b = 1 + per * (size_t)it;
             HIPCHK(hipEventElapsedTime(&v, E[b], E[b + 1])); T.local_ms += v;
             HIPCHK(hipEventElapsedTime(&v, E[b + 1], E[b + 2])); T.rhs_ms += v;
             HIPCHK(hipEventElapsedTime(&v, E[b + 2], E[b + 3])); T.allreduce_ms += v;
-            HIPCHK(hipEventElapsedTime(&v, E[b + 3], E[b + 4])); T.solve_fwd_ms += v;
-            HIPCHK(hipEventElapsedTime(&v, E[b + 4], E[b + 5])); T.solve_bwd_ms += v;
+            if (per == 7) {      // E[b+3] solve start | E[b+4] exchange start | E[b+5] exchange end | E[b+6] sweeps' midpoint | E[b+7] solve end
+                HIPCHK(hipEventElapsedTime(&v, E[b + 3], E[b + 4])); T.solve_fwd_ms += v;
+                HIPCHK(hipEventElapsedTime(&v, E[b + 4], E[b + 5])); T.allreduce_ms += v;
+                HIPCHK(hipEventElapsedTime(&v, E[b + 5], E[b + 6])); T.solve_fwd_ms += v;
+                HIPCHK(hipEventElapsedTime(&v, E[b + 6], E[b + 7])); T.solve_bwd_ms += v;
+            } else {
+                HIPCHK(hipEventElapsedTime(&v, E[b + 3], E[b + 4])); T.solve_fwd_ms += v;
+                HIPCHK(hipEventElapsedTime(&v, E[b + 4], E[b + 5])); T.solve_bwd_ms += v;
+            }
         }
         HIPCHK(hipEventElapsedTime(&v, E[need - 2], E[need - 1])); T.epilogue_ms = v;
         HIPCHK(hipEventElapsedTime(&v, E[0], E[need - 1])); T.total_ms = v;

@@ -114,28 +114,34 @@ struct ND {
     // Regions of more than `merge` nodes become FOUR-way tree nodes: the region's separator and the separators of its two
     // halves form one (dense) supernode with the four quarters as children -- half as many elimination-tree levels for the
     // zero blocks between the two half-separators.
+    // merge_root: only the whole system's region does so -- its separator and the two half-separators become ONE root
+    // supernode, which the GPU solves as a single dense product with its explicit inverse (solve_root kernels): the two
+    // top levels of both sweeps, where every launch is latency, collapse into one product.
     int merge = 0;
-    int rec(std::vector<int> &nodes) {
+    bool merge_root = false;
+    int rec(std::vector<int> &nodes, int depth = 0) {
         const int m = (int)nodes.size();
         if (m <= leaf) return emit(nodes);
-        const bool four = merge > 0 && m > merge;
+        bool four = (merge > 0 && m > merge) || (merge_root && depth == 0);
         std::vector<int> L, R, sep;
         bisect(nodes, L, R, sep);
+        // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
+        if (four && merge_root && depth == 0 && !(merge > 0 && m > merge) && 3 * sep.size() > 4096) four = false;
         std::vector<int> kids;
         std::vector<int> cols;
         if (four) {
             for (std::vector<int> *H : {&L, &R}) {
                 if (H->empty()) continue;
-                if ((int)H->size() <= leaf) { kids.push_back(rec(*H)); continue; }
+                if ((int)H->size() <= leaf) { kids.push_back(rec(*H, depth + 1)); continue; }
                 std::vector<int> a, b, sh;
                 bisect(*H, a, b, sh);
-                if (!a.empty()) kids.push_back(rec(a));
-                if (!b.empty()) kids.push_back(rec(b));
+                if (!a.empty()) kids.push_back(rec(a, depth + 2));
+                if (!b.empty()) kids.push_back(rec(b, depth + 2));
                 cols.insert(cols.end(), sh.begin(), sh.end());
             }
         } else {
-            if (!L.empty()) kids.push_back(rec(L));
-            if (!R.empty()) kids.push_back(rec(R));
+            if (!L.empty()) kids.push_back(rec(L, depth + 1));
+            if (!R.empty()) kids.push_back(rec(R, depth + 1));
         }
         cols.insert(cols.end(), sep.begin(), sep.end());
         const int s = emit(cols);
@@ -145,7 +151,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -159,7 +165,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above;
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);

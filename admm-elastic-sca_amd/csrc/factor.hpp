@@ -61,7 +61,8 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 // xyz[n][3]; fills perm/iperm, supernodes, rows, levels, gather lists.
 // merge_above > 0: regions with more nodes than that become four-way tree nodes (their separator and the two half-separators
 // in one supernode): half as many elimination-tree levels for a little more fill.
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0);
+// merge_root: the top region alone does (one root supernode = top separator + the two half-separators)
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false);
 
 // Multifrontal numeric factorization; fills F.panels.  Returns 0 or a
 // non-zero code when A is not positive definite.

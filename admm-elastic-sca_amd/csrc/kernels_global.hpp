@@ -548,6 +548,21 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restr
     }
 }
 
+// Roots of the elimination tree: x_s = (L_ss L_ss^T)^-1 t_s, both sweeps in one product.  t_s = y_s - (children's contributions)
+// is gathered once (this kernel), then dense_solve_kernel -- one wave per ROW of the symmetric inverse, every load of a row
+// independent of the others -- streams the inverse: 1089 columns in ~6 us where the tile kernel's 16 waves x 68 dependent
+// columns needed 20 us, and a merged 3335-column root (ND::merge_root) at HBM rate.
+template <bool CG2>
+__global__ __launch_bounds__(256) void root_gather_kernel(int k, int first, int64_t foff, FactorDev F, const double *__restrict__ y, const double *__restrict__ C, double *__restrict__ T) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= k) return;
+    double s0, s1, s2;
+    child_sum<CG2>(F, foff + j, C, s0, s1, s2);
+    const double *src = y + 3 * (size_t)(first + j);
+    double *t = T + 3 * (size_t)j;
+    t[0] = src[0] - s0; t[1] = src[1] - s1; t[2] = src[2] - s2;
+}
+
 // Small systems: x = A_s^-1 b with the explicit (symmetric) inverse, one wave per row, 4 rows per block; lanes stride
 // over the columns (coalesced 512-B reads of the row, 1.5 KB of b), fixed-order lane sums, transposing butterfly.
 __global__ __launch_bounds__(256) void dense_solve_kernel(int n, const double *__restrict__ Ainv, const double *__restrict__ b, double *__restrict__ X) {
@@ -557,6 +572,13 @@ __global__ __launch_bounds__(256) void dense_solve_kernel(int n, const double *_
     const double *row = Ainv + (size_t)i * n;
     double v[3] = {0.0, 0.0, 0.0};
     int j = lane;
+    for (; j + 448 < n; j += 512) {      // eight independent 512-byte row pieces in flight per wave
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = row[j + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const double *bj = b + 3 * (size_t)(j + 64 * q); v[0] += a[q] * bj[0]; v[1] += a[q] * bj[1]; v[2] += a[q] * bj[2]; }
+    }
     for (; j + 192 < n; j += 256) {
         double a[4];
 #pragma unroll
@@ -568,6 +590,36 @@ __global__ __launch_bounds__(256) void dense_solve_kernel(int n, const double *_
     int base = 0, cnt = 3;
     wave_sum_transpose<3, 32>(v, lane, base, cnt);
     if (cnt >= 1) X[3 * (size_t)i + base] = v[0];
+}
+
+// A root's product x = S^-1 t at HBM rate: one wave per row of the symmetric inverse (16 rows per block), t staged through
+// LDS in chunks of 2048 columns (read once per block instead of once per row), eight independent 512-byte row pieces in
+// flight per wave.  Fixed summation order: a lane's columns ascending, then the transposing butterfly.
+constexpr int ROOT_KCHUNK = 2048;
+__global__ __launch_bounds__(1024) void root_product_kernel(int k, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X) {
+    __shared__ double ts[ROOT_KCHUNK * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 16 + wave;
+    const double *rp = Sinv + (size_t)min(row, k - 1) * k;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < k; c0 += ROOT_KCHUNK) {
+        const int kc = min(ROOT_KCHUNK, k - c0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < 3 * kc; q += 1024) ts[q] = T[3 * (size_t)c0 + q];
+        __syncthreads();
+        int j = lane;
+        for (; j + 448 < kc; j += 512) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = rp[c0 + j + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const double *t = &ts[3 * (j + 64 * u)]; v[0] += a[u] * t[0]; v[1] += a[u] * t[1]; v[2] += a[u] * t[2]; }
+        }
+        for (; j < kc; j += 64) { const double a = rp[c0 + j]; const double *t = &ts[3 * j]; v[0] += a * t[0]; v[1] += a * t[1]; v[2] += a * t[2]; }
+    }
+    int base = 0, cnt = 3;
+    wave_sum_transpose<3, 32>(v, lane, base, cnt);
+    if (cnt >= 1 && row < k) X[3 * (size_t)row + base] = v[0];
 }
 
 } // namespace admm_dev
