@@ -82,10 +82,10 @@ struct Explicit {
 #endif
 struct LevelDev {
     int n_small = 0; admm_dev::SweepItem *d_small = nullptr;   // forward: wave items (levels below the split)
-    int n_big = 0; admm_dev::SweepItem *d_big = nullptr;       // forward: block items
+    int n_big = 0, big_nw = 16; admm_dev::SweepItem *d_big = nullptr;   // forward: block items; waves per tile (4 / 8 / 16 by the level's widest supernode)
     struct Root { int k, first; int64_t foff, inv_off; };
     std::vector<Root> roots;                                   // roots solved with their explicit inverse: gather + one row-wise product (no backward items)
-    int n_bwd = 0, bwd_cw = 1; admm_dev::SweepItem *d_bwd = nullptr;
+    int n_bwd = 0, bwd_cw = 1, bwd_nw = 4; admm_dev::SweepItem *d_bwd = nullptr;   // backward: columns per wave, waves per block
 };
 
 } // namespace
@@ -136,6 +136,9 @@ struct admm_hip_ctx {
     // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
     // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
     bool graph_enabled = true; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
+    int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
+    int bwd_nw = 8, bwd_small_nw = 4;                               // backward sweep, levels of wide supernodes: waves (= columns) per block sharing one staging (ADMM_HIP_BWD_NW = 4 / 8 / 16)
+    int fwd_nw4_kmax = 200, fwd_nw8_kmax = 400;   // forward sweep: levels whose widest supernode has at most this many columns run 4 / 8 waves per tile (ADMM_HIP_FWD_NW4 / _NW8)
     bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
     // residual tracking / early exit (off by default)
     bool res_on = false, res_ready = false;
@@ -514,15 +517,20 @@ int upload_factor(admm_hip_ctx *ctx) {
     ctx->levels.assign(F.levels.size(), LevelDev());
     // Split level: the first level holding a supernode wider than FWD_SMALL_KMAX.  Below it every forward item is
     // a wave item and the backward kernel takes 4 columns per wave; from it upwards block items / ADMM_BWD_BIG_CW.
-    int split = (int)F.levels.size();
-    for (int l = 0; l < (int)F.levels.size() && split == (int)F.levels.size(); ++l) for (int s : F.levels[l]) if (F.sn[s].ncols > admm_dev::FWD_SMALL_KMAX) { split = l; break; }
+    // Per level, by its widest supernode: forward as wave items (one wave per 64-row tile, k <= fwd_small_k <= 64) or block
+    // items (NW waves split a tile's columns); backward with 4 columns per wave (k <= bwd_small_k) or one.
+    std::vector<int> level_kmax(F.levels.size(), 0);
+    for (size_t l = 0; l < F.levels.size(); ++l) for (int s : F.levels[l]) level_kmax[l] = std::max(level_kmax[l], F.sn[s].ncols);
+    const int fwd_small_k = std::min(ctx->fwd_small_k, admm_dev::FWD_SMALL_KMAX);
     const bool subtree = ctx->shard_mode == 1 && ctx->world > 1;
     ctx->levels_top.assign(subtree ? F.levels.size() : 0, LevelDev());
     for (int pass = 0; pass < (subtree ? 2 : 1); ++pass) {      // pass 0: this rank's supernodes (all of them without subtree sharding), pass 1: the replicated top
         for (size_t l = 0; l < F.levels.size(); ++l) {
             LevelDev &L = pass == 0 ? ctx->levels[l] : ctx->levels_top[l];
             std::vector<admm_dev::SweepItem> sm, bg, bw;
-            L.bwd_cw = ((int)l < split) ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
+            const bool fwd_small = level_kmax[l] <= fwd_small_k, bwd_small = level_kmax[l] <= ctx->bwd_small_k;
+            L.bwd_cw = bwd_small ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
+            L.bwd_nw = bwd_small ? ctx->bwd_small_nw : ctx->bwd_nw;
             for (int s : F.levels[l]) {
                 if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
                 const Supernode &S = F.sn[s];
@@ -535,11 +543,16 @@ int upload_factor(admm_hip_ctx *ctx) {
                     L.roots.push_back({S.ncols, S.first, S.front_off, S.root_inv_off});
                     continue;
                 }
-                for (int t = 0; t < tiles; ++t) { it.part = t; if ((int)l < split) sm.push_back(it); else bg.push_back(it); }
-                const int chunks = (S.ncols + 4 * L.bwd_cw - 1) / (4 * L.bwd_cw);
+                for (int t = 0; t < tiles; ++t) { it.part = t; if (fwd_small) sm.push_back(it); else bg.push_back(it); }
+                const int chunks = (S.ncols + L.bwd_nw * L.bwd_cw - 1) / (L.bwd_nw * L.bwd_cw);
                 for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
             }
             L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
+            {
+                int kmax = 0;
+                for (const admm_dev::SweepItem &q : bg) kmax = std::max(kmax, q.k);
+                L.big_nw = kmax <= ctx->fwd_nw4_kmax ? 4 : (kmax <= ctx->fwd_nw8_kmax ? 8 : 16);
+            }
             TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
         }
     }
@@ -859,8 +872,10 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
                 else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
             if (L.n_big) {
-                if (F.cg4) hipLaunchKernelGGL((solve_fwd_big_kernel<true>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
-                else hipLaunchKernelGGL((solve_fwd_big_kernel<false>), dim3(L.n_big), dim3(1024), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c);
+#define ADMM_FWD_BIG(CG, NW) hipLaunchKernelGGL((solve_fwd_big_kernel<CG, NW>), dim3(L.n_big), dim3(64 * NW), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c)
+                if (F.cg4) { if (L.big_nw == 4) ADMM_FWD_BIG(true, 4); else if (L.big_nw == 8) ADMM_FWD_BIG(true, 8); else ADMM_FWD_BIG(true, 16); }
+                else { if (L.big_nw == 4) ADMM_FWD_BIG(false, 4); else if (L.big_nw == 8) ADMM_FWD_BIG(false, 8); else ADMM_FWD_BIG(false, 16); }
+#undef ADMM_FWD_BIG
             }
             for (const LevelDev::Root &R : L.roots) {      // roots: both sweeps as one product with the explicit inverse, straight into x
                 double *T = ctx->d_w + 3 * (size_t)R.first;      // the root's own slice of W is free: it has no backward launch
@@ -874,8 +889,12 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
         for (int l = (int)levels.size() - 1; l >= 0; --l) {
             const LevelDev &L = levels[l];
             if (!L.n_bwd) continue;
-            if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            if (L.bwd_cw == 4 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<4, 8>), dim3(L.n_bwd), dim3(512), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 4 && L.bwd_nw == 2) hipLaunchKernelGGL((solve_bwd_kernel<4, 2>), dim3(L.n_bwd), dim3(128), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<1, 8>), dim3(L.n_bwd), dim3(512), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_nw == 16) hipLaunchKernelGGL((solve_bwd_kernel<1, 16>), dim3(L.n_bwd), dim3(1024), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
         }
     };
@@ -1015,6 +1034,12 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
     if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_GRAPH_COMM")) ctx->graph_comm = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
+    if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
+    if (const char *g = getenv("ADMM_HIP_FWD_NW4")) ctx->fwd_nw4_kmax = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_FWD_NW8")) ctx->fwd_nw8_kmax = atoi(g);
     if (const char *g = getenv("ADMM_HIP_DENSE_MAX")) ctx->dense_max = atoi(g);
     if (const char *g = getenv("ADMM_HIP_ROOT_INVERSE")) ctx->root_inverse = atoi(g) != 0;
     *out = ctx;

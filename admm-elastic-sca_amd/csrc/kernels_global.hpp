@@ -355,15 +355,19 @@ __global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_ker
     }
 }
 
-// Forward sweep, supernodes with k > 64: one 1024-thread block = one
-// (supernode, 64-row tile); the 16 waves split the columns, partial sums are
-// combined through LDS in wave order.
-constexpr int FWD_BIG_KCHUNK = 2048;
-template <bool CG2>
-__global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__restrict__ items,
+// Forward sweep, supernodes with k > 64: one block of NW waves = one
+// (supernode, 64-row tile); the waves split the columns, partial sums are
+// combined through LDS in wave order.  NW = 16 for the wide supernodes at the top of the tree; levels of narrower ones run
+// with 4 or 8 waves per tile (chosen per level from its widest supernode, admm_hip.hip upload_factor): a CU holds the same
+// number of waves either way, but four times as many tiles are resident at once and every wave has a full group of columns
+// to stream instead of a handful -- such levels are bound by the per-tile prologue latency, not by bytes.
+template <int NW> struct FwdBig { static constexpr int KCHUNK = NW == 16 ? 2048 : 512; };
+template <bool CG2, int NW>
+__global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem *__restrict__ items,
                                                              FactorDev F, const double *__restrict__ y, double *__restrict__ W, double *__restrict__ C) {
+    constexpr int FWD_BIG_KCHUNK = FwdBig<NW>::KCHUNK, NT = 64 * NW;
     __shared__ double ts[FWD_BIG_KCHUNK * 3];
-    __shared__ double red[16][64 * 3];
+    __shared__ double red[NW][64 * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const SweepItem it = items[blockIdx.x];
     const int tile = it.part, k = it.k, r = it.r, first = it.first;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int c0 = 0; c0 < kneed; c0 += FWD_BIG_KCHUNK) {
         const int kc = min(FWD_BIG_KCHUNK, kneed - c0);
-        const int per = (kc + 15) >> 4;
+        const int per = (kc + NW - 1) / NW;
         const int jb = c0 + wave * per;
         int je = min(jb + per, c0 + kc);
         je = row_ok ? min(je, jend) : jb;
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__
 #pragma unroll
         for (int q = 0; q < D; ++q) cur[q] = (jb + q < je) ? P[(size_t)f * (jb + q)] : 0.0;
         __syncthreads();
-        for (int q = threadIdx.x; q < kc; q += 1024) {
+        for (int q = threadIdx.x; q < kc; q += NT) {
             const double *src = y + 3 * (size_t)(first + c0 + q);
             double s0, s1, s2;
             child_sum<CG2>(F, foff + c0 + q, C, s0, s1, s2);
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(1024) void solve_fwd_big_kernel(const SweepItem *__
         if (row < f) {
             double acc = red[0][3 * ln + c];
 #pragma unroll
-            for (int w = 1; w < 16; ++w) acc += red[w][3 * ln + c];
+            for (int w = 1; w < NW; ++w) acc += red[w][3 * ln + c];
             if (row < k) W[3 * (size_t)(first + row) + c] = acc;
             else C[3 * (size_t)(it.slot_off + (row - k)) + c] = acc + carry;
         }
@@ -471,8 +475,10 @@ __device__ __forceinline__ void wave_sum_transpose(double *v, int lane, int &bas
 }
 
 constexpr int BWD_RCHUNK = 1024;
-template <int CW>
-__global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restrict__ items,
+// NWB waves per block share one staging of the vector (4 is the original shape; 8 / 16 halve / quarter the staging work
+// per column on levels of tall fronts).
+template <int CW, int NWB = 4>
+__global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__restrict__ items,
                                                         FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
     __shared__ double vs[BWD_RCHUNK * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restr
     const int chunk = it.part, k = it.k, r = it.r, first = it.first;
     const int f = k + r;
     const int *rows = F.rows + it.rows_off;
-    const int jc0 = chunk * (4 * CW);           // first column of this block
+    const int jc0 = chunk * (NWB * CW);         // first column of this block
     const int j0 = jc0 + wave * CW;             // this wave's first column
     const double *Pj = F.panels + it.panel_off + (size_t)f * min(j0, k - 1);
     double acc[CW][3];
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(256) void solve_bwd_kernel(const SweepItem *__restr
     for (int r0 = jc0; r0 < f; r0 += BWD_RCHUNK) {
         const int rc = min(BWD_RCHUNK, f - r0);
         __syncthreads();
-        for (int q = threadIdx.x; q < rc; q += 256) {
+        for (int q = threadIdx.x; q < rc; q += 64 * NWB) {
             const int i = r0 + q;
             double v0, v1, v2;
             if (i < k) { const double *src = W + 3 * (size_t)(first + i); v0 = src[0]; v1 = src[1]; v2 = src[2]; }
