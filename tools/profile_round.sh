@@ -1,26 +1,37 @@
 #!/bin/bash
-# GPU box: the round's judged artefacts in one go -> gpurun_out/{pmc_1M.json, bench_1M.json, bench_1M_under_rocprof.json, bench_1M_kernel_stats.csv,
-# level_trace_1M.txt, bench_mixed.json}; copy them into profiles/rNN/ afterwards.
+# GPU box: the round's judged artefacts in one go -> gpurun_out/prof/{pmc_1M.json, bench_1M.json, bench_1M_under_rocprof.json,
+# bench_1M_kernel_stats.csv, level_trace_1M.txt, level_trace_fake8.txt, per_rank_kernel_time_fake_world.txt, bench_mixed.json};
+# copy them into profiles/rNN/ afterwards.   usage: tools/profile_round.sh [rNN]
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+R=${1:-r02}
+O=gpurun_out/prof
+mkdir -p $O
 export TMPDIR=/tmp
-# 1. PMC passes first: bench.py quotes roofline.traffic / roofline.valu from profiles/r01/pmc_1M.json, so refresh that file (on this box) before the bench line is made
-bash tools/pmc_collect.sh
-cp gpurun_out/pmc_1M.json profiles/r01/pmc_1M.json
+# 1. PMC passes first: bench.py quotes roofline.traffic / roofline.valu from profiles/$R/pmc_1M.json (labelled as such in the
+#    line), so refresh that file on this box before the bench line is made
+bash tools/pmc_collect.sh > $O/pmc_collect.log 2>&1
+mkdir -p profiles/$R && cp gpurun_out/pmc_1M.json profiles/$R/pmc_1M.json && cp gpurun_out/pmc_1M.json $O/pmc_1M.json
 # 2. the bench line
-python bench.py > gpurun_out/bench_1M.json 2> gpurun_out/bench_1M.err
-tail -1 gpurun_out/bench_1M.json | cut -c1-400
+ADMM_BENCH_PMC=$R/pmc_1M.json python bench.py > $O/bench_1M.json 2> $O/bench_1M.err
+tail -1 $O/bench_1M.json | cut -c1-300
 # 3. the same command under rocprofv3 --kernel-trace --stats
 rm -rf /tmp/prof_stats
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/bench_1M_under_rocprof.json 2>/dev/null)
-cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) gpurun_out/bench_1M_kernel_stats.csv
-head -12 gpurun_out/bench_1M_kernel_stats.csv | cut -c1-160
-# 4. per-level picture of one ADMM iteration + the mixed scene
-ADMM_HIP_VERBOSE=1 python tools/run_steps.py 32 32 163 1 2>&1 | grep "admm_hip: level" > gpurun_out/level_trace_1M.txt
-python tools/level_trace.py /tmp/prof_stats >> gpurun_out/level_trace_1M.txt 2>&1
-tail -12 gpurun_out/level_trace_1M.txt
-python bench.py --config mixed > gpurun_out/bench_mixed.json 2>/dev/null
-tail -1 gpurun_out/bench_mixed.json | cut -c1-200
-# 5. where a tet-kernel wave spends its life (instrumented variant build)
-python tools/tet_phase_profile.py frames=2 > gpurun_out/tet_phase_profile.txt 2>&1
-tail -11 gpurun_out/tet_phase_profile.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/bench_1M_under_rocprof.json 2>/dev/null)
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_1M_kernel_stats.csv
+head -14 $O/bench_1M_kernel_stats.csv | cut -c1-160
+# 4. per-level picture of one ADMM iteration (eager launches), the mixed scene
+ADMM_HIP_VERBOSE=1 python tools/run_steps.py 32 32 163 1 2>&1 | grep "admm_hip: level" > $O/level_trace_1M.txt
+rm -rf /tmp/prof_trace
+(cd /tmp && ADMM_HIP_GRAPH=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1)
+python tools/level_trace.py /tmp/prof_trace >> $O/level_trace_1M.txt 2>&1
+tail -12 $O/level_trace_1M.txt
+python bench.py --config mixed --no-extras > $O/bench_mixed.json 2>/dev/null
+tail -1 $O/bench_mixed.json | cut -c1-200
+# 5. what ONE rank of a 2 / 4 / 8-rank run computes per iteration (no-op all-reduce), and one rank's launches of an 8-rank run
+bash tools/fake_world.sh > $O/per_rank_kernel_time_fake_world.txt 2>&1
+for g in 0 1; do
+  BENCH_TIMING_EXPERIMENT=1 ADMM_HIP_GRAPH_COMM=$g ADMM_BENCH_FAKE_WORLD=8 ADMM_BENCH_FAKE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 \
+    bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>/dev/null | python3 tools/bench_summary.py "world8-subtree-rank0-rccl-in-library-graphcomm$g" >> $O/per_rank_kernel_time_fake_world.txt
+done
+cat $O/per_rank_kernel_time_fake_world.txt
+bash tools/fake_world_trace.sh 8 > /dev/null 2>&1; cp gpurun_out/level_trace_fake8.txt $O/level_trace_fake8.txt
