@@ -138,6 +138,7 @@ struct admm_hip_ctx {
     bool graph_enabled = true; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     int bwd_nw = 8, bwd_small_nw = 4;                               // backward sweep, levels of wide supernodes: waves (= columns) per block sharing one staging (ADMM_HIP_BWD_NW = 4 / 8 / 16)
+    int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
     int fwd_nw4_kmax = 200, fwd_nw8_kmax = 400;   // forward sweep: levels whose widest supernode has at most this many columns run 4 / 8 waves per tile (ADMM_HIP_FWD_NW4 / _NW8)
     bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
     // residual tracking / early exit (off by default)
@@ -530,7 +531,11 @@ int upload_factor(admm_hip_ctx *ctx) {
             std::vector<admm_dev::SweepItem> sm, bg, bw;
             const bool fwd_small = level_kmax[l] <= fwd_small_k, bwd_small = level_kmax[l] <= ctx->bwd_small_k;
             L.bwd_cw = bwd_small ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
-            L.bwd_nw = bwd_small ? ctx->bwd_small_nw : ctx->bwd_nw;
+            // eight columns per block pay where a level has thousands of columns (one staging of the vector per 8 instead of 4
+            // columns); on levels with few columns the larger number of blocks matters more (50k-tet bar: 4 waves 222 us / 8: 228)
+            int level_cols = 0;
+            for (int s : F.levels[l]) if (!subtree || ctx->sn_owner[s] == (pass == 0 ? ctx->rank : -1)) level_cols += F.sn[s].ncols;
+            L.bwd_nw = bwd_small ? ctx->bwd_small_nw : (level_cols >= ctx->bwd_nw_min_cols ? ctx->bwd_nw : 4);
             for (int s : F.levels[l]) {
                 if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
                 const Supernode &S = F.sn[s];
@@ -551,7 +556,8 @@ int upload_factor(admm_hip_ctx *ctx) {
             {
                 int kmax = 0;
                 for (const admm_dev::SweepItem &q : bg) kmax = std::max(kmax, q.k);
-                L.big_nw = kmax <= ctx->fwd_nw4_kmax ? 4 : (kmax <= ctx->fwd_nw8_kmax ? 8 : 16);
+                // few tiles (all resident at once even with 16 waves each): the more waves share a tile's columns the shorter its chain
+                L.big_nw = (int)bg.size() <= ctx->fwd_nw16_max_tiles ? 16 : (kmax <= ctx->fwd_nw4_kmax ? 4 : (kmax <= ctx->fwd_nw8_kmax ? 8 : 16));
             }
             TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
         }
@@ -1038,6 +1044,8 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
+    if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW4")) ctx->fwd_nw4_kmax = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW8")) ctx->fwd_nw8_kmax = atoi(g);
     if (const char *g = getenv("ADMM_HIP_DENSE_MAX")) ctx->dense_max = atoi(g);
