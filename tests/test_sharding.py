@@ -364,3 +364,90 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert len(pr["local_ms"]) == 2 and min(pr["total_ms"]) > 0 and sum(pr["elements"]) == 8 * 8 * 40 * 6 + 9 * 9
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
+
+
+def _spring_net(n=9, h=0.1):
+    """The net of tests/cpp/user_force.cpp: n x n nodes, springs to the +x, +z and diagonal neighbours."""
+    x = np.zeros((n * n, 3))
+    for j in range(n):
+        for i in range(n):
+            x[i + n * j] = (h * i, 0.02 * np.sin(0.7 * i + 0.3 * j), h * j)
+    pairs = []
+    for j in range(n):
+        for i in range(n):
+            q = i + n * j
+            for nb in (q + 1 if i + 1 < n else -1, q + n if j + 1 < n else -1, q + n + 1 if (i + 1 < n and j + 1 < n) else -1):
+                if nb >= 0:
+                    pairs.append((q, nb))
+    return x, np.array(pairs, np.int32)
+
+
+def _user_spring_system(pkg, x, pairs, k, rank=0, world=1, mode=None, generic=True):
+    """Springs as USER forces through the generic batch (selector rows as triplets, project() = a numpy hook doing Spring's
+    arithmetic, Force.cpp:52-71, on this rank's elements), or as the built-in kind."""
+    s = pkg.System(device_id=0); s.set_timestep(0.04)
+    s.add_nodes(x.ravel(), np.full(x.size, 0.05))
+    ne = pairs.shape[0]
+    w = np.sqrt(k)
+    if generic:
+        rows = np.repeat(np.arange(ne) * 3, 3) + np.tile(np.arange(3), ne)          # element e owns rows 3e..3e+2
+        tr = np.concatenate([rows, rows]).astype(np.int32)
+        tc = np.concatenate([3 * np.repeat(pairs[:, 0], 3) + np.tile(np.arange(3), ne), 3 * np.repeat(pairs[:, 1], 3) + np.tile(np.arange(3), ne)]).astype(np.int32)
+        tv = np.concatenate([np.ones(3 * ne), -np.ones(3 * ne)])
+        b = s.add_generic(np.arange(ne + 1) * 3, tr, tc, tv, np.full(3 * ne, w))
+        d0 = x[pairs[:, 0]] - x[pairs[:, 1]]
+        rest = np.sqrt(d0[:, 0] * d0[:, 0] + (d0[:, 1] * d0[:, 1] + d0[:, 2] * d0[:, 2]))
+        state = {}
+
+        def project(dt, Dx, u, z):
+            ids = state.setdefault("ids", s.local_elements(b))        # this rank's user forces
+            r = (3 * ids[:, None] + np.arange(3)[None, :])
+            dx = Dx[r]; d = dx + u[r]
+            nrm = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]))
+            c = 1.0 / (w * w + k)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                dn = np.where(nrm[:, None] <= 0.0, 0.0, d / nrm[:, None])
+            zi = c * (k * (rest[ids][:, None] * dn) + (w * w) * d)
+            u[r] += (dx - zi)
+            z[r] = zi
+        s.set_project_hook(project)
+    else:
+        s.add_forces(pkg.KIND["SPRING"], pairs, [k])
+    n = int(round(np.sqrt(x.shape[0])))
+    s.add_forces(pkg.KIND["ANCHOR"], np.array([0, n - 1], np.int32), [-1.0, 1.0])
+    s.add_gravity([0, -9.8, 0])
+    if world > 1:
+        s.set_shard(rank, world)
+        s.set_shard_mode(mode)
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "subtree"), (3, "subtree"), (2, "contiguous")])
+def test_user_forces_sharded(pkg, monkeypatch, world, mode):
+    """User-defined forces (generic batch + project hook) under sharding: every rank projects its own user forces, the device
+    evaluates D_i x for their rows and adds their shares of the right-hand side.  Unsharded the user springs equal the built-in
+    spring kernel bit for bit; sharded they agree with the unsharded run to rounding and all ranks end bitwise identical."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "8")
+    x, pairs = _spring_net(11)
+    k = 400.0
+    builtin = _user_spring_system(pkg, x, pairs, k, generic=False); builtin.initialize()
+    ref = _user_spring_system(pkg, x, pairs, k); ref.initialize()
+    refx = []
+    for _ in range(3):
+        builtin.step(10); ref.step(10)
+        assert np.array_equal(builtin.m_x, ref.m_x)
+        refx.append(ref.m_x.copy())
+    shards = [_user_spring_system(pkg, x, pairs, k, rank=r, world=world, mode=mode) for r in range(world)]
+    hooks = _thread_allreduce_hooks(world)
+    for r, s in enumerate(shards):
+        s.set_allreduce(hooks[r])
+        s.initialize()
+    assert sorted(np.concatenate([s.local_elements(0) for s in shards]).tolist()) == list(range(pairs.shape[0]))     # every user force on exactly one rank
+    out = _run_sharded(shards, 3, 10, np.zeros(3 * ref.n_nodes))
+    for r in range(world):
+        _, xs, vs = out[r]
+        for f in range(3):
+            assert np.abs(xs[f] - refx[f]).max() < 1e-9, (r, f)
+        assert np.array_equal(xs[-1], out[0][1][-1]) and np.array_equal(vs, out[0][2])
