@@ -152,8 +152,9 @@ struct admm_hip_ctx {
     double *d_gen_dx = nullptr, *d_gen_q = nullptr;                 // [n_gen_rows]
     double *h_gen_dx = nullptr, *h_gen_u = nullptr, *h_gen_z = nullptr, *h_gen_q = nullptr;   // pinned
     hipEvent_t gen_ev = nullptr;
-    // timing
-    bool timing = false;
+    // timing: HIP events around the phases of every timing_stride-th ADMM iteration (1 = every iteration); an event is a
+    // barrier packet that costs ~5 us of launch overlap, so the other iterations run event-free (as a graph replay when one exists)
+    bool timing = false; int timing_stride = 1; int ev_timed = 0;
     std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
     size_t ev_used = 0; int ev_iters = 0; bool ev_pending = false;
     admm_hip_timing last_timing{};
@@ -1358,8 +1359,8 @@ int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets,
 }
 
 // records the next pooled event on the stream (timing mode only)
-static int mark(admm_hip_ctx *ctx) {
-    if (!ctx->timing) return ADMM_OK;
+static int mark(admm_hip_ctx *ctx, bool on = true) {
+    if (!ctx->timing || !on) return ADMM_OK;
     if (ctx->ev_used == ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
     HIPCHK(hipEventRecord(ctx->evpool[ctx->ev_used++], ctx->stream));
     return ADMM_OK;
@@ -1370,8 +1371,8 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     using namespace admm_dev;
     HIPCHK(hipSetDevice(ctx->device_id));
     const int n3 = 3 * ctx->n_nodes;
-    // event layout (timing mode): E0 | prologue | E1 | per iter: local E rhs E allreduce E fwd E bwd E | epilogue | E
-    ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_pending = ctx->timing;
+    // event layout (timing mode): E0 | prologue | E1 | per TIMED iteration: S local E rhs E allreduce E [exchange: E E] fwd E bwd E | Ea | epilogue | Eb
+    ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_timed = 0; ctx->ev_pending = ctx->timing;
     TRY(mark(ctx));
     if (ctx->explicit_simple) {
         hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
@@ -1397,7 +1398,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     // world > 1: the iteration contains an all-reduce.  A host hook cannot be captured; ncclAllReduce can (RCCL collectives are
     // stream-ordered device work), so with the communicator inside the library the multi-GPU iteration is one graph launch too.
     const bool comm_capturable = ctx->world == 1 || (ctx->rccl_comm != nullptr && ctx->graph_comm);
-    const bool use_graph = ctx->graph_enabled && comm_capturable && !ctx->timing && !track && admm_iters > 0 && !ctx->n_gen_rows;
+    const bool use_graph = ctx->graph_enabled && comm_capturable && !(ctx->timing && ctx->timing_stride <= 1) && !track && admm_iters > 0 && !ctx->n_gen_rows;
     if (use_graph && !ctx->iter_exec) {   // capture one iteration; every kernel argument is a fixed device address
         // a stream that cannot be captured (caller-supplied, already capturing ...) is not an error: launch eagerly instead
         const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
@@ -1415,31 +1416,35 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     }
     ctx->res_n = 0;
     int iters_done = 0;
+    const int stride = std::max(1, ctx->timing_stride);
     for (int it = 0; it < admm_iters; ++it) {
-        if (use_graph && ctx->iter_exec) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
+        const bool timed = ctx->timing && (it % stride == stride - 1);
+        if (use_graph && ctx->iter_exec && !timed) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
+        if (timed) ++ctx->ev_timed;
+        TRY(mark(ctx, timed));
         if (track) TRY(residual_snapshot(ctx, it == 0));
         TRY(generic_begin(ctx, ctx->d_xcur));
         TRY(launch_local(ctx));
         TRY(generic_finish(ctx));
-        TRY(mark(ctx));
+        TRY(mark(ctx, timed));
         if (track) { TRY(launch_residuals(ctx, it)); ctx->res_n = it + 1; }
         TRY(launch_rhs(ctx));
-        TRY(mark(ctx));
+        TRY(mark(ctx, timed));
         if (ctx->world > 1 && ctx->levels_top.empty()) {     // contiguous sharding: the whole RHS is summed, the solve is replicated
             TRY(do_allreduce(ctx, ctx->d_y, (int64_t)n3));
         }
-        TRY(mark(ctx));
+        TRY(mark(ctx, timed));
         // timing mode: one event between the sweeps; under subtree sharding two more around the exchange inside the forward
         // sweep (pack, all-reduce, unpack), so that allreduce_ms shows the communication and solve_fwd_ms only the sweeps
         hipEvent_t mid = nullptr, ex0 = nullptr, ex1 = nullptr;
-        if (ctx->timing) {
+        if (timed) {
             const int want = ctx->levels_top.empty() ? 1 : 3;
             while (ctx->ev_used + want > ctx->evpool.size()) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evpool.push_back(e); }
             if (want == 3) { ex0 = ctx->evpool[ctx->ev_used++]; ex1 = ctx->evpool[ctx->ev_used++]; }
             mid = ctx->evpool[ctx->ev_used++];
         }
         TRY(launch_solve(ctx, mid, ex0, ex1));
-        TRY(mark(ctx));
+        TRY(mark(ctx, timed));
         iters_done = it + 1;
         if (ctx->tol_r > 0.0 && (it + 1) % ctx->check_every == 0 && it + 1 < admm_iters) {   // convergence test: one round trip
             double rs[2];
@@ -1449,6 +1454,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         }
     }
     ctx->ev_iters = iters_done;
+    TRY(mark(ctx));
     TRY(shard_sync_x(ctx));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
     HIPCHK(hipGetLastError());
@@ -1734,6 +1740,7 @@ int admm_hip_get_residuals(admm_hip_ctx *ctx, double *r_norm, double *s_norm, in
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->timing = on != 0;
+    ctx->timing_stride = on > 1 ? on : 1;      // on = k > 1: events around every k-th ADMM iteration only
     return ADMM_OK;
 }
 // Reads back the events of the last step recorded in timing mode (waits for it).
@@ -1742,19 +1749,19 @@ int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t) {
     if (ctx->ev_pending && ctx->device_id >= 0) {
         HIPCHK(hipSetDevice(ctx->device_id));
         const std::vector<hipEvent_t> &E = ctx->evpool;
-        const size_t per = ctx->levels_top.empty() ? 5 : 7;       // events per ADMM iteration (see admm_hip_step)
-        const size_t need = 3 + per * (size_t)ctx->ev_iters;
+        const size_t per = ctx->levels_top.empty() ? 6 : 8;       // events per TIMED ADMM iteration (see admm_hip_step)
+        const size_t need = 4 + per * (size_t)ctx->ev_timed;
         if (ctx->ev_used != need) return fail(ctx, ADMM_ERR_STATE, "timing events incomplete (%zu of %zu)", ctx->ev_used, need);
         HIPCHK(hipEventSynchronize(E[need - 1]));
         admm_hip_timing T{};
         float v;
         HIPCHK(hipEventElapsedTime(&v, E[0], E[1])); T.prologue_ms = v;
-        for (int it = 0; it < ctx->ev_iters; ++it) {
-            const size_t b = 1 + per * (size_t)it;
+        for (int it = 0; it < ctx->ev_timed; ++it) {
+            const size_t b = 2 + per * (size_t)it;
             HIPCHK(hipEventElapsedTime(&v, E[b], E[b + 1])); T.local_ms += v;
             HIPCHK(hipEventElapsedTime(&v, E[b + 1], E[b + 2])); T.rhs_ms += v;
             HIPCHK(hipEventElapsedTime(&v, E[b + 2], E[b + 3])); T.allreduce_ms += v;
-            if (per == 7) {      // E[b+3] solve start | E[b+4] exchange start | E[b+5] exchange end | E[b+6] sweeps' midpoint | E[b+7] solve end
+            if (per == 8) {      // E[b+3] solve start | E[b+4] exchange start | E[b+5] exchange end | E[b+6] sweeps' midpoint | E[b+7] solve end
                 HIPCHK(hipEventElapsedTime(&v, E[b + 3], E[b + 4])); T.solve_fwd_ms += v;
                 HIPCHK(hipEventElapsedTime(&v, E[b + 4], E[b + 5])); T.allreduce_ms += v;
                 HIPCHK(hipEventElapsedTime(&v, E[b + 5], E[b + 6])); T.solve_fwd_ms += v;
@@ -1766,6 +1773,10 @@ int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t) {
         }
         HIPCHK(hipEventElapsedTime(&v, E[need - 2], E[need - 1])); T.epilogue_ms = v;
         HIPCHK(hipEventElapsedTime(&v, E[0], E[need - 1])); T.total_ms = v;
+        if (ctx->ev_timed > 0 && ctx->ev_timed != ctx->ev_iters) {      // sampled: phase sums scaled to the whole frame (total_ms is the real span)
+            const float sc = (float)ctx->ev_iters / (float)ctx->ev_timed;
+            T.local_ms *= sc; T.rhs_ms *= sc; T.allreduce_ms *= sc; T.solve_fwd_ms *= sc; T.solve_bwd_ms *= sc;
+        }
         T.iters = ctx->ev_iters;
         ctx->last_timing = T;
         ctx->ev_pending = false;

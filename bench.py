@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--shard", choices=["subtree", "contiguous"], default="subtree",
                    help="N > 1: subtree = ranks own elimination subtrees + their elements, small per-iteration exchange (default); "
                         "contiguous = element ranges, full RHS all-reduce, replicated solve")
+    p.add_argument("--timing-stride", type=int, default=4, help="HIP events around every k-th ADMM iteration of the timed region (1 = every iteration, all launches eager)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the class-API frame cost and the other BASELINE configs (N = 1 only)")
     p.add_argument("--cpu-dims", type=int, nargs=3, default=[16, 16, 65], help="bounded CPU-baseline sample (cubes)")
@@ -283,7 +284,10 @@ def main():
     for _ in range(a.warmup):
         s.step(ADMM_ITERS)
     sync_all()
-    s.enable_timing(True)  # HIP events recorded on the solver's stream, read back after the region
+    # HIP events on the solver's stream around the phases of every TIMING_STRIDE-th ADMM iteration of the timed region (read
+    # back after each frame); the other iterations replay the captured graph.  An event is a barrier packet (~5 us of lost
+    # launch overlap each): around every iteration they cost 1.7 % at one GPU and ~10 % of a rank's 0.35 ms at eight.
+    s.enable_timing(a.timing_stride)
     phase = dict(local_ms=0.0, rhs_ms=0.0, allreduce_ms=0.0, solve_fwd_ms=0.0, solve_bwd_ms=0.0, total_ms=0.0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -355,7 +359,9 @@ def main():
                                ("mixed scene: bar %dx%dx%d (half NH, half StVK tets) + 158x158 sym-plane cloth (triangle strain + bend) + anchors = %d "
                                 "tets+tris, %d nodes, %d ADMM iters/frame" % (nx, ny, nz, n_tets, info["n_nodes"], ADMM_ITERS)),
                    "admm_iters_per_step": ADMM_ITERS,
-                   "launch_mode": "eager launches with HIP events between the phases (the events feed roofline; the event-free default replays one HIP graph per iteration)",
+                   "launch_mode": ("every ADMM iteration launched eagerly with HIP events between its phases" if a.timing_stride <= 1 else
+                                   "HIP events between the phases of every %d-th ADMM iteration (eager launches; %d samples per kernel feed roofline), "
+                                   "one graph replay per iteration otherwise" % (a.timing_stride, a.steps * (ADMM_ITERS // a.timing_stride))),
                    "allreduce": (comm_path if (world > 1 or fake_dist) else None), "parallelism": ("1 GPU" if world == 1 else
                                    ("x%d: elements and elimination subtrees per rank, one small all-reduce (top separators) per ADMM iteration, top of the solve replicated" % world
                                     if a.shard == "subtree" else "x%d: contiguous element shards, RHS all-reduce per ADMM iteration, replicated solve" % world)),

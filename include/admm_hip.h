@@ -255,6 +255,9 @@ typedef struct admm_hip_timing {
     float prologue_ms, local_ms, rhs_ms, allreduce_ms, solve_fwd_ms, solve_bwd_ms, epilogue_ms, total_ms;
     int32_t iters;
 } admm_hip_timing;
+/* on = 1: events around the phases of every ADMM iteration (eager launches); on = k > 1: around every k-th iteration only
+ * -- a HIP event is a barrier packet that costs ~5 us of launch overlap -- the other iterations run event-free (one graph
+ * replay each where a graph exists) and the phase sums are scaled to the frame; total_ms is always the real span.      */
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on);
 int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t);
 
