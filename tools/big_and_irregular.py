@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""GPU box: two sanity workloads beyond the benchmark -- the 4M-tet bar (64x64x163 cubes: 5 GB of panels) and an unstructured
+Delaunay mesh of ~1M NH tets (150,000 random points in a 1x1x4 box) -- ms per ADMM iteration, phases, levels."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+pkg = load_package()
+
+
+def run(s, n_el, label):
+    t0 = time.time(); s.initialize(); ti = time.time() - t0
+    s.step(20); s.sync()
+    s.enable_timing(4)
+    ph = dict(local_ms=0.0, rhs_ms=0.0, solve_fwd_ms=0.0, solve_bwd_ms=0.0)
+    t = time.perf_counter()
+    for _ in range(3):
+        s.step(20)
+        tm = s.timing()
+        for k in ph:
+            ph[k] += tm[k] / 60
+    s.sync()
+    t = (time.perf_counter() - t) / 60
+    assert np.isfinite(s.m_x).all()
+    inf = s.info()
+    print(label, "elements %d nodes %d nnzL %.3g levels %d initialize %.1fs  ms/iter %.3f  iters/s x el %.4g " % (n_el, inf["n_nodes"], inf["nnz_L"], inf["n_levels"], ti, 1e3 * t, n_el / t),
+          {k: round(v, 3) for k, v in ph.items()}, flush=True)
+
+
+which = sys.argv[1:] or ["delaunay", "bar4m"]
+if "delaunay" in which:
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 1, size=(150000, 3)) * np.array([1.0, 1.0, 4.0])
+    tets = Delaunay(pts).simplices.astype(np.int32)
+    e = pts[tets]
+    vol = np.einsum("ij,ij->i", e[:, 1] - e[:, 0], np.cross(e[:, 2] - e[:, 0], e[:, 3] - e[:, 0])) / 6.0
+    tets[vol < 0] = tets[vol < 0][:, [0, 1, 3, 2]]
+    tets = tets[np.abs(vol) > 1e-4 * np.abs(vol).mean()]
+    m = pkg.meshgen.lumped_tet_mass(pts, tets, 1000.0)
+    s = pkg.System(device_id=0); s.set_timestep(0.04)
+    s.add_nodes(pts.ravel(), np.repeat(m, 3))
+    s.add_forces(pkg.KIND["TET_NH"], tets, [1e5, 1e5, 5])
+    s.add_forces(pkg.KIND["ANCHOR"], np.nonzero(pts[:, 2] < 0.05)[0].astype(np.int32), [-1.0, 1.0])
+    s.add_gravity((0.0, -9.8, 0.0))
+    run(s, tets.shape[0], "delaunay 150k points:")
+    del s
+if "bar4m" in which:
+    s = pkg.make_bar_system(64, 64, 163)
+    run(s, s.n_tets, "bar 64x64x163:")
