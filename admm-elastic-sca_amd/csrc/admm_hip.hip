@@ -154,7 +154,7 @@ struct admm_hip_ctx {
     hipEvent_t gen_ev = nullptr;
     // timing: HIP events around the phases of every timing_stride-th ADMM iteration (1 = every iteration); an event is a
     // barrier packet that costs ~5 us of launch overlap, so the other iterations run event-free (as a graph replay when one exists)
-    bool timing = false; int timing_stride = 1; int ev_timed = 0;
+    bool timing = false; int timing_stride = 1; int ev_timed = 0; int timing_frame = 0;
     std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
     size_t ev_used = 0; int ev_iters = 0; bool ev_pending = false;
     admm_hip_timing last_timing{};
@@ -1418,7 +1418,9 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     int iters_done = 0;
     const int stride = std::max(1, ctx->timing_stride);
     for (int it = 0; it < admm_iters; ++it) {
-        const bool timed = ctx->timing && (it % stride == stride - 1);
+        // the sampled iterations rotate from frame to frame: an iteration's cost depends on its position in the frame (the first
+        // ones after the prologue do the most line-search work), a fixed phase would bias the average
+        const bool timed = ctx->timing && ((it + ctx->timing_frame) % stride == stride - 1);
         if (use_graph && ctx->iter_exec && !timed) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
         if (timed) ++ctx->ev_timed;
         TRY(mark(ctx, timed));
@@ -1454,6 +1456,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         }
     }
     ctx->ev_iters = iters_done;
+    if (ctx->timing) ++ctx->timing_frame;
     TRY(mark(ctx));
     TRY(shard_sync_x(ctx));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
@@ -1741,6 +1744,7 @@ int admm_hip_enable_timing(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->timing = on != 0;
     ctx->timing_stride = on > 1 ? on : 1;      // on = k > 1: events around every k-th ADMM iteration only
+    ctx->timing_frame = 0;
     return ADMM_OK;
 }
 // Reads back the events of the last step recorded in timing mode (waits for it).
