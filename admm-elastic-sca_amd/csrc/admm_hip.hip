@@ -263,29 +263,38 @@ int idx_stride(int kind) {
 // K (x) I3: no coupling between coordinates and the same K for x, y and z.  Checked per element, refused loudly otherwise.
 int assemble_generic(admm_hip_ctx *ctx, const Batch &b, std::vector<int> &ti, std::vector<int> &tj, std::vector<double> &tv) {
     const double dt = ctx->dt;
-    std::vector<double> K;
+    struct Ent { int a, c, comp; double v; };      // (node a >= node c, coordinate) -> dt^2 sum_r D(r, a) w_r^2 D(r, c); sparse: an element may span all nodes
+    std::vector<Ent> ent;
     for (int e = 0; e < b.n_total; ++e) {
         const int32_t *nodes; const int nn = b.elem_nodes(e, &nodes);
         if (nn && nodes[nn - 1] >= ctx->n_nodes) return fail(ctx, ADMM_ERR_ARG, "user-defined force %d references node %d (have %d nodes)", e, nodes[nn - 1], ctx->n_nodes);
-        K.assign((size_t)3 * nn * nn, 0.0);
+        ent.clear();
         double cross = 0.0, kmax = 0.0;
         for (int64_t r = b.g_elem_row[e]; r < b.g_elem_row[e + 1]; ++r) {
             const double w = b.g_roww[r];
             for (int64_t p = b.g_rowptr[r]; p < b.g_rowptr[r + 1]; ++p) for (int64_t q = b.g_rowptr[r]; q < b.g_rowptr[r + 1]; ++q) {
-                const int np_ = b.g_col[p] / 3, cp = b.g_col[p] % 3, nq = b.g_col[q] / 3, cq = b.g_col[q] % 3;
+                const int na = b.g_col[p] / 3, cp = b.g_col[p] % 3, nc = b.g_col[q] / 3, cq = b.g_col[q] % 3;
                 const double t = (((dt * dt) * b.g_val[p]) * w) * w * b.g_val[q];
                 if (cp != cq) { cross = std::max(cross, std::fabs(t)); continue; }
-                const int a = (int)(std::lower_bound(nodes, nodes + nn, np_) - nodes), c = (int)(std::lower_bound(nodes, nodes + nn, nq) - nodes);
-                K[((size_t)cp * nn + a) * nn + c] += t;
+                if (na >= nc) ent.push_back({na, nc, cp, t});
             }
         }
-        for (double v : K) kmax = std::max(kmax, std::fabs(v));
+        std::stable_sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.a != y.a ? x.a < y.a : (x.c != y.c ? x.c < y.c : x.comp < y.comp); });
+        // reduce runs of equal (a, c, comp), then compare the three coordinates of every (a, c)
+        std::vector<Ent> red;
+        for (const Ent &x : ent) { if (!red.empty() && red.back().a == x.a && red.back().c == x.c && red.back().comp == x.comp) red.back().v += x.v; else red.push_back(x); }
+        for (const Ent &x : red) kmax = std::max(kmax, std::fabs(x.v));
         double dev = 0.0;
-        for (size_t i = 0; i < (size_t)nn * nn; ++i) dev = std::max(dev, std::max(std::fabs(K[i] - K[(size_t)nn * nn + i]), std::fabs(K[i] - K[2 * (size_t)nn * nn + i])));
+        for (size_t i = 0; i < red.size();) {
+            size_t j = i; double k3[3] = {0.0, 0.0, 0.0};
+            for (; j < red.size() && red[j].a == red[i].a && red[j].c == red[i].c; ++j) k3[red[j].comp] = red[j].v;
+            dev = std::max(dev, std::max(std::fabs(k3[0] - k3[1]), std::fabs(k3[0] - k3[2])));
+            ti.push_back(red[i].a); tj.push_back(red[i].c); tv.push_back(k3[0]);
+            i = j;
+        }
         if (cross > 1e-12 * kmax || dev > 1e-12 * kmax)
             return fail(ctx, ADMM_ERR_UNSUPPORTED, "user-defined force %d of a generic batch: D^T W^2 D is not of the form K (x) I3 (coordinate coupling %.3g, x/y/z mismatch %.3g of %.3g); "
                         "the accelerated path factors the scalar system", e, cross, dev, kmax);
-        for (int a = 0; a < nn; ++a) for (int c = 0; c <= a; ++c) { ti.push_back(nodes[a]); tj.push_back(nodes[c]); tv.push_back(K[(size_t)a * nn + c]); }
     }
     return ADMM_OK;
 }
@@ -657,14 +666,22 @@ int upload_all(admm_hip_ctx *ctx) {
                     for (int64_t p = b.g_rowptr[r]; p < b.g_rowptr[r + 1]; ++p) { col.push_back(3 * F.iperm[b.g_col[p] / 3] + b.g_col[p] % 3); val.push_back(b.g_val[p]); }
                     rptr.push_back((int)col.size());
                 }
+                // the element's entries by column (ascending row inside a column): one pass, an element may span all nodes
+                std::vector<std::pair<int32_t, int64_t> > bycol;      // (column, entry)
+                for (int64_t rr = b.g_elem_row[e]; rr < b.g_elem_row[e + 1]; ++rr) for (int64_t p = b.g_rowptr[rr]; p < b.g_rowptr[rr + 1]; ++p) bycol.push_back({b.g_col[p], p});
+                std::stable_sort(bycol.begin(), bycol.end(), [](const std::pair<int32_t, int64_t> &x, const std::pair<int32_t, int64_t> &y) { return x.first < y.first; });
+                std::vector<int64_t> entry_row(b.g_rowptr[b.g_elem_row[e + 1]] - b.g_rowptr[b.g_elem_row[e]]);
+                for (int64_t rr = b.g_elem_row[e]; rr < b.g_elem_row[e + 1]; ++rr) for (int64_t p = b.g_rowptr[rr]; p < b.g_rowptr[rr + 1]; ++p) entry_row[p - b.g_rowptr[b.g_elem_row[e]]] = rr;
+                size_t q = 0;
                 for (int c = 0; c < nn; ++c) {
                     const int pn = F.iperm[nd[c]];
                     const int64_t r = inc_pos[pn]++;
                     sdst.push_back(ctx->slot_stride ? (int)((r - inc_ptr[pn]) * ctx->slot_stride + pn) : (int)r);
                     for (int comp = 0; comp < 3; ++comp) {
-                        for (int64_t rr = b.g_elem_row[e]; rr < b.g_elem_row[e + 1]; ++rr)
-                            for (int64_t p = b.g_rowptr[rr]; p < b.g_rowptr[rr + 1]; ++p)
-                                if (b.g_col[p] == 3 * nd[c] + comp) { srow.push_back((int)(b.g_row0 + rr)); b.g_srow_b.push_back((int32_t)rr); b.g_sval.push_back(b.g_val[p]); }
+                        for (; q < bycol.size() && bycol[q].first == 3 * nd[c] + comp; ++q) {
+                            const int64_t p = bycol[q].second, rr = entry_row[p - b.g_rowptr[b.g_elem_row[e]]];
+                            srow.push_back((int)(b.g_row0 + rr)); b.g_srow_b.push_back((int32_t)rr); b.g_sval.push_back(b.g_val[p]);
+                        }
                         sptr.push_back((int)srow.size());
                     }
                 }
