@@ -135,7 +135,10 @@ struct admm_hip_ctx {
     // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
     // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
     // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
-    bool graph_enabled = true; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
+    // Default (graph_forced = false): only for systems of < 100k nodes, where an iteration is ~20 short dependent kernels and the
+    // host's launch work matters; at 1M tets the GPU is the limit and a replay is 0.5-2 % SLOWER than the same launches issued
+    // eagerly (0.780 vs 0.766-0.775 ms per iteration, tools/graph_vs_eager.py).  ADMM_HIP_GRAPH=1 forces it, 0 disables it.
+    bool graph_enabled = true, graph_forced = false; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     int bwd_nw = 8, bwd_small_nw = 4;                               // backward sweep, levels of wide supernodes: waves (= columns) per block sharing one staging (ADMM_HIP_BWD_NW = 4 / 8 / 16)
     int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
@@ -1056,7 +1059,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     ctx->info.device_id = device_id; ctx->info.world = 1;
     const char *ls = getenv("ADMM_HIP_LEAF");
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
-    if (const char *g = getenv("ADMM_HIP_GRAPH")) ctx->graph_enabled = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_GRAPH")) { ctx->graph_enabled = atoi(g) != 0; ctx->graph_forced = ctx->graph_enabled; }
     if (const char *g = getenv("ADMM_HIP_GRAPH_COMM")) ctx->graph_comm = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
@@ -1415,7 +1418,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     // world > 1: the iteration contains an all-reduce.  A host hook cannot be captured; ncclAllReduce can (RCCL collectives are
     // stream-ordered device work), so with the communicator inside the library the multi-GPU iteration is one graph launch too.
     const bool comm_capturable = ctx->world == 1 || (ctx->rccl_comm != nullptr && ctx->graph_comm);
-    const bool use_graph = ctx->graph_enabled && comm_capturable && !(ctx->timing && ctx->timing_stride <= 1) && !track && admm_iters > 0 && !ctx->n_gen_rows;
+    const bool use_graph = ctx->graph_enabled && (ctx->graph_forced || ctx->n_nodes < 100000) && comm_capturable && !(ctx->timing && ctx->timing_stride <= 1) && !track && admm_iters > 0 && !ctx->n_gen_rows;
     if (use_graph && !ctx->iter_exec) {   // capture one iteration; every kernel argument is a fixed device address
         // a stream that cannot be captured (caller-supplied, already capturing ...) is not an error: launch eagerly instead
         const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);

@@ -361,7 +361,7 @@ def main():
                    "admm_iters_per_step": ADMM_ITERS,
                    "launch_mode": ("every ADMM iteration launched eagerly with HIP events between its phases" if a.timing_stride <= 1 else
                                    "HIP events between the phases of every %d-th ADMM iteration (eager launches; %d samples per kernel feed roofline), "
-                                   "one graph replay per iteration otherwise" % (a.timing_stride, a.steps * (ADMM_ITERS // a.timing_stride))),
+                                   "event-free launches otherwise (eager at this size; one graph replay per iteration below 100k nodes)" % (a.timing_stride, a.steps * (ADMM_ITERS // a.timing_stride))),
                    "allreduce": (comm_path if (world > 1 or fake_dist) else None), "parallelism": ("1 GPU" if world == 1 else
                                    ("x%d: elements and elimination subtrees per rank, one small all-reduce (top separators) per ADMM iteration, top of the solve replicated" % world
                                     if a.shard == "subtree" else "x%d: contiguous element shards, RHS all-reduce per ADMM iteration, replicated solve" % world)),
@@ -395,7 +395,7 @@ def main():
         tr = (time.perf_counter() - tr) / a.steps
         s.pin_host(hx, False); s.pin_host(hv, False)
         out["class_api"] = {"ms_per_step": 1e3 * tc, "resident_ms_per_step": 1e3 * tr, "value": ADMM_ITERS / tc * n_tets, "overhead_frac": tc / tr - 1.0,
-                            "what": "admm_hip_upload_state(m_x, m_v) + admm_hip_step + admm_hip_download_state(m_x, m_v) per frame, graph replay, "
+                            "what": "admm_hip_upload_state(m_x, m_v) + admm_hip_step + admm_hip_download_state(m_x, m_v) per frame, event-free, "
                                     "vs. the same %d frames with the state resident" % a.steps}
         out["other_configs"] = other_configs(pkg, torch, a.steps)
     if rank == 0:
