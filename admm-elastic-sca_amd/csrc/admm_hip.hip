@@ -371,7 +371,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // Under subtree sharding what counts is a rank's share: 8 ranks of the 178.6k-node bar (22k nodes each) run 4 % faster with
         // leaves of 128 (per-rank kernel time 0.438 -> 0.421 ms, tools/fake_world.sh with ADMM_HIP_LEAF), 4 ranks are indifferent.
         const int64_t share = ctx->n_nodes / std::max(1, ctx->world);
-        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->world > 1 ? (share < 25000 ? 128 : 64) : (ctx->n_nodes < 25000 ? 256 : 64));
+        // (round 2, with this round's sweep kernels: per-rank forward + backward at 8 ranks, leaves 64 / 128 / 256 / 384 / 512:
+        //  0.248 / 0.239 / 0.229 / 0.226 / 0.234 ms; at 4 ranks 64 / 128 / 256 / 384: 0.275 / 0.270 / 0.265 / 0.260; at 2 ranks 64 is best)
+        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->world > 1 ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 25000 ? 256 : 64));
         // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
         int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
