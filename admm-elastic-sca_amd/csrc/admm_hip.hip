@@ -370,10 +370,11 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // 44k nodes 334 / 318 / 321 / 322, 178.6k nodes 982 / 954 / 1026 / 1020.
         // Under subtree sharding what counts is a rank's share: 8 ranks of the 178.6k-node bar (22k nodes each) run 4 % faster with
         // leaves of 128 (per-rank kernel time 0.438 -> 0.421 ms, tools/fake_world.sh with ADMM_HIP_LEAF), 4 ranks are indifferent.
+        const bool own_subtrees = ctx->world > 1 && ctx->shard_mode == ADMM_SHARD_SUBTREE;     // contiguous sharding replicates the whole solve: one GPU's choice
         const int64_t share = ctx->n_nodes / std::max(1, ctx->world);
         // (round 2, with this round's sweep kernels: per-rank forward + backward at 8 ranks, leaves 64 / 128 / 256 / 384 / 512:
         //  0.248 / 0.239 / 0.229 / 0.226 / 0.234 ms; at 4 ranks 64 / 128 / 256 / 384: 0.275 / 0.270 / 0.265 / 0.260; at 2 ranks 64 is best)
-        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (ctx->world > 1 ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 25000 ? 256 : 64));
+        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (own_subtrees ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 25000 ? 256 : 64));
         // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
         int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
@@ -1317,10 +1318,10 @@ int admm_hip_finalize(admm_hip_ctx *ctx) {
     if (ctx->n_nodes < 1 || ctx->m3.size() != ctx->x.size()) return fail(ctx, ADMM_ERR_ARG, "**Solver Error: Problem with node data!");
     std::fill(ctx->v.begin(), ctx->v.end(), 0.0); // System.cpp:113
     for (const Explicit &E : ctx->explicits) for (int32_t v : E.idx) if (v >= ctx->n_nodes) return fail(ctx, ADMM_ERR_ARG, "explicit force references node %d (have %d)", v, ctx->n_nodes);
+    if (const char *e = getenv("ADMM_HIP_SHARD")) ctx->shard_mode = (std::string(e) == "subtree") ? ADMM_SHARD_SUBTREE : ADMM_SHARD_CONTIGUOUS;
     TRY(host_assemble(ctx, false));
     TRY(host_factor(ctx, false));
     ctx->info.rank = ctx->rank; ctx->info.world = ctx->world;
-    if (const char *e = getenv("ADMM_HIP_SHARD")) ctx->shard_mode = (std::string(e) == "subtree") ? ADMM_SHARD_SUBTREE : ADMM_SHARD_CONTIGUOUS;
     if (ctx->dense) ctx->shard_mode = 0;          // small systems: one-kernel solve, nothing to shard
     partition_subtrees(ctx);
     assign_elements(ctx);
