@@ -911,7 +911,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
                 double *T = ctx->d_w + 3 * (size_t)R.first;      // the root's own slice of W is free: it has no backward launch
                 if (F.cg4) hipLaunchKernelGGL((root_gather_kernel<true>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
                 else hipLaunchKernelGGL((root_gather_kernel<false>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
-                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + 15) / 16), dim3(1024), 0, ctx->stream, R.k, (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
+                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + ROOT_ROWS - 1) / ROOT_ROWS), dim3(64 * ROOT_ROWS), 0, ctx->stream, R.k, root_inv_ld(R.k), (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
             }
         }
     };

@@ -421,9 +421,9 @@ int factorize(const SymCSC &A, Factor &F, int threads) {
             Supernode &S = F.sn[s];
             S.root_inv_off = -1;
             if (S.parent >= 0 || S.nrows != 0 || S.ncols <= ROOT_INV_MIN_COLS) continue;
-            const int k = S.ncols;
-            const size_t off = F.panels.size();
-            F.panels.resize(off + (size_t)k * k);
+            const int k = S.ncols, ld = root_inv_ld(k);
+            const size_t off = (F.panels.size() + 15) & ~(size_t)15;
+            F.panels.resize(off + (size_t)ld * k, 0.0);
             const double *Li = F.panels.data() + S.panel_off;      // L^-1, lower triangular, ld = k
             double *Si = F.panels.data() + off;
 #pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
@@ -432,7 +432,7 @@ int factorize(const SymCSC &A, Factor &F, int threads) {
                     double acc = 0.0;
                     const double *ci = Li + (size_t)k * i, *cj = Li + (size_t)k * j;
                     for (int m = i; m < k; ++m) acc += ci[m] * cj[m];
-                    Si[i + (size_t)k * j] = acc; Si[j + (size_t)k * i] = acc;
+                    Si[i + (size_t)ld * j] = acc; Si[j + (size_t)ld * i] = acc;
                 }
             S.root_inv_off = (int64_t)off;
         }

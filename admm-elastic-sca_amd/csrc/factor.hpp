@@ -34,9 +34,11 @@ struct Supernode {
     int64_t panel_off = 0;  // into Factor::panels (doubles), ld = ncols + nrows
     int64_t slot_off = 0;   // first contribution slot
     int64_t front_off = 0;  // index of the supernode's first front row (k + r rows) in the global front-row numbering
-    int64_t root_inv_off = -1; // roots with more than ROOT_INV_MIN_COLS columns: offset in Factor::panels of (L_ss L_ss^T)^-1, k x k, full, column-major
+    int64_t root_inv_off = -1; // roots with more than ROOT_INV_MIN_COLS columns: offset in Factor::panels of (L_ss L_ss^T)^-1, k x k, full (symmetric), leading dimension root_inv_ld(k)
 };
 constexpr int ROOT_INV_MIN_COLS = 64;
+// leading dimension of a root's explicit inverse: rows start on 128-byte lines (16-byte loads per lane in root_product_kernel)
+inline int root_inv_ld(int k) { return (k + 15) & ~15; }
 
 struct Factor {
     int n = 0;

@@ -601,18 +601,48 @@ __global__ __launch_bounds__(256) void dense_solve_kernel(int n, const double *_
 // A root's product x = S^-1 t at HBM rate: one wave per row of the symmetric inverse (16 rows per block), t staged through
 // LDS in chunks of 2048 columns (read once per block instead of once per row), eight independent 512-byte row pieces in
 // flight per wave.  Fixed summation order: a lane's columns ascending, then the transposing butterfly.
+#ifndef ADMM_ROOT_VEC2
+#define ADMM_ROOT_VEC2 1
+#endif
 constexpr int ROOT_KCHUNK = 2048;
-__global__ __launch_bounds__(1024) void root_product_kernel(int k, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X) {
-    __shared__ double ts[ROOT_KCHUNK * 3];
+#ifndef ADMM_ROOT_ROWS
+#define ADMM_ROOT_ROWS 16         // rows (= waves) per block of root_product_kernel: one staging of t per block (4 / 8 / 16 rows: 37 / 22 / 20 us at k = 3301)
+#endif
+constexpr int ROOT_ROWS = ADMM_ROOT_ROWS;
+__global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X) {
+    __shared__ double ts[ROOT_KCHUNK * 3 + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 16 + wave;
-    const double *rp = Sinv + (size_t)min(row, k - 1) * k;
+    const int row = blockIdx.x * ROOT_ROWS + wave;
+    const double *rp = Sinv + (size_t)min(row, k - 1) * ld;      // ld is a multiple of 16 doubles: every row starts on a 128-byte line
     double v[3] = {0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < k; c0 += ROOT_KCHUNK) {
         const int kc = min(ROOT_KCHUNK, k - c0);
         __syncthreads();
-        for (int q = threadIdx.x; q < 3 * kc; q += 1024) ts[q] = T[3 * (size_t)c0 + q];
+        for (int q = threadIdx.x; q < 3 * kc; q += 64 * ROOT_ROWS) ts[q] = T[3 * (size_t)c0 + q];
+        if (kc & 1) { if (threadIdx.x < 3) ts[3 * kc + threadIdx.x] = 0.0; }      // the pair loads below may reach one column past an odd chunk (padding of the row: finite)
         __syncthreads();
+#if ADMM_ROOT_VEC2
+        // 16 bytes per lane and load: a wave covers 128 columns per instruction, eight instructions in flight
+        const double2 *rp2 = reinterpret_cast<const double2 *>(rp + c0);
+        const int kc2 = (kc + 1) >> 1;
+        int j = lane;
+        for (; j + 448 < kc2; j += 512) {
+            double2 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = rp2[j + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double *t = &ts[6 * (j + 64 * u)];
+                v[0] += a[u].x * t[0]; v[1] += a[u].x * t[1]; v[2] += a[u].x * t[2];
+                v[0] += a[u].y * t[3]; v[1] += a[u].y * t[4]; v[2] += a[u].y * t[5];
+            }
+        }
+        for (; j < kc2; j += 64) {
+            const double2 a = rp2[j]; const double *t = &ts[6 * j];
+            v[0] += a.x * t[0]; v[1] += a.x * t[1]; v[2] += a.x * t[2];
+            v[0] += a.y * t[3]; v[1] += a.y * t[4]; v[2] += a.y * t[5];
+        }
+#else
         int j = lane;
         for (; j + 448 < kc; j += 512) {
             double a[8];
@@ -622,6 +652,7 @@ __global__ __launch_bounds__(1024) void root_product_kernel(int k, const double 
             for (int u = 0; u < 8; ++u) { const double *t = &ts[3 * (j + 64 * u)]; v[0] += a[u] * t[0]; v[1] += a[u] * t[1]; v[2] += a[u] * t[2]; }
         }
         for (; j < kc; j += 64) { const double a = rp[c0 + j]; const double *t = &ts[3 * j]; v[0] += a * t[0]; v[1] += a * t[1]; v[2] += a * t[2]; }
+#endif
     }
     int base = 0, cnt = 3;
     wave_sum_transpose<3, 32>(v, lane, base, cnt);
