@@ -778,3 +778,34 @@ def test_irregular_delaunay_mesh(pkg, monkeypatch):
         assert np.isfinite(s.m_x).all()
         xs.append(s.m_x.copy())
     assert np.array_equal(xs[0], xs[1])                       # both slot layouts, bit for bit
+
+
+def test_state_boundary_and_sampled_timing(pkg):
+    """The class API's frame boundary (admm_hip_upload_state / download_state: one DMA per vector out of / into page-locked
+    caller memory, reordering to the factor's node order on the device) against get/set; and timing events around every k-th
+    iteration only: same trajectory bit for bit, phase sums scaled to the frame and consistent with the frame's real span."""
+    s = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"])
+    s.initialize()
+    ref = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"])
+    ref.initialize()
+    n3 = 3 * s.n_nodes
+    hx = np.empty(n3); hv = np.empty(n3)
+    s.pin_host(hx); s.pin_host(hv)
+    rng = np.random.default_rng(4)
+    x0 = s.m_x * (1.0 + 1e-3 * rng.normal(size=n3)); v0 = 1e-2 * rng.normal(size=n3)
+    hx[:] = x0; hv[:] = v0
+    s.upload_state(hx, hv)
+    assert np.array_equal(s.m_x, x0) and np.array_equal(s.m_v, v0)          # upload == set
+    ref.m_x = x0; ref.m_v = v0
+    s.enable_timing(3)                                                        # events around every 3rd iteration
+    for f in range(3):
+        s.upload_state(hx, hv); s.step(10); s.download_state(hx, hv)
+        ref.step(10)
+        assert np.array_equal(hx, ref.m_x) and np.array_equal(hv, ref.m_v)  # download == get; sampled timing changes nothing
+        t = s.timing()
+        assert t["iters"] == 10 and t["total_ms"] > 0
+        phases = t["local_ms"] + t["rhs_ms"] + t["allreduce_ms"] + t["solve_fwd_ms"] + t["solve_bwd_ms"]
+        assert 0.3 * t["total_ms"] < phases < 2.0 * t["total_ms"]
+    s.upload_state(hx, None)                                                  # one vector alone
+    assert np.array_equal(s.m_v, ref.m_v)
+    s.pin_host(hx, False); s.pin_host(hv, False)
