@@ -474,7 +474,10 @@ __device__ __forceinline__ void wave_sum_transpose(double *v, int lane, int &bas
     if constexpr (off > 1) wave_sum_transpose<h, off / 2>(v, lane, base, cnt);
 }
 
-constexpr int BWD_RCHUNK = 1024;
+#ifndef ADMM_BWD_RCHUNK
+#define ADMM_BWD_RCHUNK 1024
+#endif
+constexpr int BWD_RCHUNK = ADMM_BWD_RCHUNK;
 // NWB waves per block share one staging of the vector (4 is the original shape; 8 / 16 halve / quarter the staging work
 // per column on levels of tall fronts).
 template <int CW, int NWB = 4>
