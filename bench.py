@@ -165,17 +165,26 @@ def install_rccl(s, torch, dist, rank, world, local_rank):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if float(flag.item()) < 1.0:
         raise RuntimeError("ncclGetUniqueId failed on rank 0")
-    state = {"ok": False}
+    state = {"ok": False, "cancel": False}
+    lock = threading.Lock()
 
     def init():     # collective; the library selects the context's device before ncclCommInitRank
         try:
             s.rccl_init(uid, rank, world)
-            state["ok"] = True
         except Exception as e:  # noqa: BLE001
             print("bench: rank %d: %r" % (rank, e), file=sys.stderr)
+            return
+        with lock:      # a communicator that arrives after the deadline must not stay installed: the other ranks have moved on
+            if state["cancel"]:
+                s.set_rccl_comm(None)
+            else:
+                state["ok"] = True
     th = threading.Thread(target=init, daemon=True)
     th.start()
     th.join(timeout=float(os.environ.get("ADMM_BENCH_RCCL_INIT_TIMEOUT", "120")))
+    with lock:
+        if not state["ok"]:
+            state["cancel"] = True
     flag.fill_(1.0 if state["ok"] else 0.0)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     good = float(flag.item()) >= 1.0
