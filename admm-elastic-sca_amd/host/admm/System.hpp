@@ -284,7 +284,10 @@ protected:
         const size_t bytes = sizeof(double) * (size_t)n_rows;
         std::memcpy(self->user_Dx.data(), Dx, bytes); std::memcpy(self->user_u.data(), u, bytes); std::memcpy(self->user_z.data(), z, bytes);
         const int nf = (int)self->user_local.size();
-#pragma omp parallel for
+        // a team sized to the work (one thread per 512 forces, at most 16): this runs once per ADMM iteration between two GPU
+        // phases, and the default team -- every hardware thread of the host, 128+ -- costs milliseconds to wake for microseconds of work
+        int team = nf / 512; team = team > 16 ? 16 : (team < 1 ? 1 : team);
+#pragma omp parallel for num_threads(team) if (team > 1) schedule(static)
         for (int i = 0; i < nf; ++i) self->forces[self->user_local[i]]->project(dt, self->user_Dx, self->user_u, self->user_z);
         std::memcpy(u, self->user_u.data(), bytes); std::memcpy(z, self->user_z.data(), bytes);
         return 0;

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <memory>
 #include <vector>
 
@@ -150,12 +151,19 @@ int main(int argc, char **argv) {
     if (!system.initialize()) return 2;
     FILE *f = std::fopen(argv[2], "wb");
     if (!f) return 4;
+    const std::clock_t c0 = std::clock();
+    struct timespec w0, w1;
+    clock_gettime(CLOCK_MONOTONIC, &w0);
     for (int fr = 0; fr < frames; ++fr) {
         if (!system.step()) { std::fclose(f); return 3; }
         std::fwrite(system.m_x.data(), sizeof(double), 3 * n * n, f);
     }
+    clock_gettime(CLOCK_MONOTONIC, &w1);
+    (void)c0;
+    const double wall = (w1.tv_sec - w0.tv_sec) + 1e-9 * (w1.tv_nsec - w0.tv_nsec);
     for (size_t i = 0; i < mine.size(); ++i) { const double gw[2] = {(double)mine[i]->global_idx, mine[i]->weight}; std::fwrite(gw, sizeof(double), 2, f); }
     std::fclose(f);
-    std::printf("user_force: mode %d, %d nodes, %zu forces (%zu user), %d frames x %d iterations\n", mode, n * n, system.forces.size(), mine.size(), frames, iters);
+    std::printf("user_force: mode %d, %d nodes, %zu forces (%zu user), %d frames x %d iterations, %.1f us per ADMM iteration\n", mode, n * n, system.forces.size(), mine.size(), frames, iters,
+                1e6 * wall / (frames * (double)iters));
     return 0;
 }
