@@ -80,14 +80,28 @@ def cpu_baseline(dims):
     assert s.initialize()
     t_init = time.time() - t0
     s.time_steps(1)  # warm-up frame
-    frames = 2
-    sec = s.time_steps(frames)
-    cores = checkers.Ref.load().ref_omp_threads() if kind == "reference" else (os.cpu_count() or 1)
+    # the reference parallelises its local step with an OpenMP team of every hardware thread by default; on a 256-thread host
+    # that is 3.6x slower than a moderate team (149.7 vs 41-43 ms per iteration on this sample): time a few team sizes on
+    # consecutive frames and report the BEST one -- the baseline at its best, with the count it used
+    lib = s.lib
+    setter = getattr(lib, ("ref_" if kind == "reference" else "orc_") + "set_omp_threads", None)
+    getter = getattr(lib, ("ref_" if kind == "reference" else "orc_") + "omp_threads")
+    hw = os.cpu_count() or 1
+    tried = {}
+    teams = sorted({t for t in (16, 64, getter(), hw) if 1 <= t <= hw}) if setter is not None else [getter()]
+    frames = 1 if len(teams) > 1 else 2
+    for team in teams:
+        if setter is not None:
+            setter(int(team))
+        tried[int(team)] = s.time_steps(frames) / frames
+    cores = min(tried, key=tried.get)
+    sec = tried[cores] * frames
     val = frames * ADMM_ITERS / sec * tets.shape[0]
     out = {"value": val, "unit": "ADMM iters/s x elements", "cores": int(cores), "kind": kind,
-           "sample": "NH bar %dx%dx%d cubes = %d tets, %d frames x %d ADMM iters after 1 warm-up frame; initialize() %.1f s excluded; "
+           "sample": "NH bar %dx%dx%d cubes = %d tets, %d frame(s) x %d ADMM iters per OpenMP team size after 1 warm-up frame, best team reported; initialize() %.1f s excluded; "
                      "%.1f ms/iter" % (nx, ny, nz, tets.shape[0], frames, ADMM_ITERS, t_init, 1e3 * sec / (frames * ADMM_ITERS)),
-           "ms_per_iter": 1e3 * sec / (frames * ADMM_ITERS), "cpu_model": _cpu_model()}
+           "ms_per_iter": 1e3 * sec / (frames * ADMM_ITERS), "cpu_model": _cpu_model(), "hardware_threads": hw,
+           "ms_per_iter_by_team": {str(k): 1e3 * v / ADMM_ITERS for k, v in sorted(tried.items())}}
     if kind == "reference":       # which binary this was: built by oracle/Makefile from /root/reference in the build container
         import hashlib
         so = os.path.join(ROOT, "oracle", "_ref", "libadmm_ref.so")

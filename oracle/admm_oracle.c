@@ -1328,6 +1328,9 @@ void orc_get_D(orc_system *s, int *rows, int *cols, double *vals) {
 }
 long orc_L_nnz(orc_system *s) { return s->Lp ? s->Lp[s->dof] : 0; }
 
+void orc_set_omp_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_omp_threads(void) { return omp_get_max_threads(); }
+
 double orc_time_steps(orc_system *s, int frames) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -96,6 +96,8 @@ double *orc_wdiag(orc_system *s);
 long orc_D_nnz(orc_system *s);
 void orc_get_D(orc_system *s, int *rows, int *cols, double *vals); /* in push order */
 long orc_L_nnz(orc_system *s);
+void orc_set_omp_threads(int n);   /* team size of the local-step loop (bench.py cpu_baseline tries a few) */
+int orc_omp_threads(void);
 double orc_time_steps(orc_system *s, int frames);
 
 #ifdef __cplusplus

@@ -287,5 +287,8 @@ double ref_time_steps(void *h, int frames) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 int ref_omp_threads() { return omp_get_max_threads(); }
+// bench.py's cpu_baseline times the reference with a few team sizes and reports the best one (a team of every hardware
+// thread of a 256-thread host is 3.6x slower than 16-64 threads on the 100k-tet sample)
+void ref_set_omp_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 } // extern "C"
