@@ -125,6 +125,9 @@ __global__ void permute_out_kernel(int n_nodes, const int *__restrict__ perm, co
 // its slot (layouts: admm_hip.hip upload_all), summed here in fixed (batch, element, corner) order.
 // base = M x_bar exactly once across ranks: on rank 0 (contiguous sharding: add_base), or where base_mask says this
 // rank is responsible for the node (subtree sharding: the owner of the node's subtree; rank 0 for the replicated top).
+#ifndef ADMM_RHS_UNROLL
+#define ADMM_RHS_UNROLL 1
+#endif
 __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr, int slot_stride,
                                   const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base,
                                   const unsigned char *__restrict__ base_mask, double *__restrict__ y) {
@@ -136,7 +139,17 @@ __global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_p
     if (slot_stride) {      // rank-major slots: lane i reads word i of every rank's array
         const int deg = (int)(p1 - p0);
         const double *f = fslot + i;
-        for (int r = 0; r < deg; ++r) acc += f[3 * (size_t)r * slot_stride];
+        int r = 0;
+#if ADMM_RHS_UNROLL
+        for (; r + 8 <= deg; r += 8) {      // eight independent loads in flight; the sum keeps its order
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = f[3 * (size_t)(r + q) * slot_stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += t[q];
+        }
+#endif
+        for (; r < deg; ++r) acc += f[3 * (size_t)r * slot_stride];
     } else {
         for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
     }
