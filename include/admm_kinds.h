@@ -19,6 +19,8 @@
  *   COLLISION     CollisionForce (one element per node)  CollisionForce.cpp:27-70  1    3
  *   TRI_AREA      TriArea                      TriangleForce.cpp:257-295 3    6
  *   TRI_FUNG      FungTriangle                 TriangleForce.cpp:120-249 3    6
+ *   GENERIC       any user-written admm::Force subclass  Force.hpp:37-57   (rows and nodes per element as its
+ *                 get_selector says; project() runs in the caller's hook: admm_hip_add_generic_batch)
  *
  * "rows" are the compact rows of D/u/z per element.  (The reference gives
  * every tet 36 rows of which 27 are structurally zero -- TetForce.cpp:61 vs
