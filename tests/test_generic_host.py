@@ -71,3 +71,16 @@ def test_element_over_all_nodes_assembles_in_linear_time(pkg):
     assert inf["nnz_A"] == n and inf["rows_compact"] == 3 * n      # diagonal: mass + dt^2 w^2
     v = np.ones(3 * n)
     assert np.allclose(s.apply_A(v), 1.0 + 0.04 * 0.04 * 32.0 * 32.0)
+
+
+def test_duplicate_triplets_are_summed(pkg):
+    """Eigen's setFromTriplets sums duplicates (System.cpp:125); so does the generic batch."""
+    n = 6
+    pairs = np.array([(0, 1), (2, 5), (3, 4)], np.int32)
+    erp, tr, tc, tv = _spring_triplets(pairs)
+    a, x = _sys(pkg, n)
+    a.add_generic(erp, tr, tc, tv, np.full(9, 2.0)); a.initialize()
+    b, _ = _sys(pkg, n, x)
+    b.add_generic(erp, np.concatenate([tr, tr]), np.concatenate([tc, tc]), np.concatenate([0.25 * tv, 0.75 * tv]), np.full(9, 2.0)); b.initialize()
+    v = np.random.default_rng(3).normal(size=3 * n)
+    assert np.allclose(a.apply_A(v), b.apply_A(v), rtol=0, atol=1e-15) and a.info()["nnz_A"] == b.info()["nnz_A"]
