@@ -809,3 +809,27 @@ def test_state_boundary_and_sampled_timing(pkg):
     s.upload_state(hx, None)                                                  # one vector alone
     assert np.array_equal(s.m_v, ref.m_v)
     s.pin_host(hx, False); s.pin_host(hv, False)
+
+
+def test_checkpoint_resume_is_bitwise(pkg):
+    """The solver's state between frames is (m_x, m_v, u of every force, the hyperelastic warm start last_prox_result + init_hess):
+    the reference cannot serialise it (its save() writes geometry only); through the C ABI a fresh context that
+    receives this state continues the trajectory bit for bit."""
+    def make():
+        s, _ = pkg.make_mixed_system(4, 3, 10, 8, 6)
+        s.initialize()
+        return s
+    a = make()
+    for _ in range(3):
+        a.step(10)
+    ck = dict(x=a.m_x.copy(), v=a.m_v.copy(), loc=[a.read_local(b) for b in range(len(a.batches))])
+    for _ in range(2):
+        a.step(10)
+    b = make()
+    b.m_x = ck["x"]; b.m_v = ck["v"]
+    for bi, loc in enumerate(ck["loc"]):
+        kind = b.batches[bi][0]
+        b.write_local(bi, u=loc["u"], state=loc["state"] if pkg.KIND_STATE[kind] else None)
+    for _ in range(2):
+        b.step(10)
+    assert np.array_equal(a.m_x, b.m_x) and np.array_equal(a.m_v, b.m_v)
