@@ -61,7 +61,7 @@ struct Batch {
     int g_lrows = 0, g_lslots = 0;        // this rank's rows / (element, node) slots
     std::vector<double> g_sval; std::vector<int32_t> g_srow_b;   // per slot entry: D value and batch row (coefficients are rebuilt on recompute_weights)
     int *d_g_lrow = nullptr, *d_g_rptr = nullptr, *d_g_col = nullptr, *d_g_sptr = nullptr, *d_g_srow = nullptr, *d_g_sdst = nullptr;
-    double *d_g_val = nullptr, *d_g_scoef = nullptr;
+    double *d_g_val = nullptr, *d_g_scoef = nullptr, *d_g_scoef_res = nullptr;   // (_res: val * w^2, the dual residual's coefficients)
     int elem_nodes(int e, const int32_t **p) const {
         if (kind == ADMM_KIND_GENERIC) { *p = g_nodes.data() + g_elem_node[e]; return (int)(g_elem_node[e + 1] - g_elem_node[e]); }
         *p = idx.data() + (size_t)e * ADMM_KIND_NODES[kind]; return ADMM_KIND_NODES[kind];
@@ -154,6 +154,7 @@ struct admm_hip_ctx {
     int64_t n_gen_rows = 0;
     double *d_gen_dx = nullptr, *d_gen_q = nullptr;                 // [n_gen_rows]
     double *h_gen_dx = nullptr, *h_gen_u = nullptr, *h_gen_z = nullptr, *h_gen_q = nullptr;   // pinned
+    std::vector<double> h_gen_u_prev, h_gen_z_prev; double *d_gen_q2 = nullptr, *d_gen_r2 = nullptr;   // residual tracking of the user rows
     hipEvent_t gen_ev = nullptr;
     // timing: HIP events around the phases of every timing_stride-th ADMM iteration (1 = every iteration); an event is a
     // barrier packet that costs ~5 us of launch overlap, so the other iterations run event-free (as a graph replay when one exists)
@@ -965,16 +966,26 @@ int shard_sync_x(admm_hip_ctx *ctx) {
 
 // ---- residual tracking (opt-in): buffers are created on first use -------------------------------------
 int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
-    if (ctx->n_gen_rows) return fail(ctx, ADMM_ERR_UNSUPPORTED, "residual tracking is not available with user-defined forces (their u and z live on the host)");
     if (ctx->res_ready && iters <= ctx->res_cap) return ADMM_OK;
     HIPCHK(hipSetDevice(ctx->device_id));
     if (!ctx->res_ready) {
         int64_t slots = 0; int maxn = 0;
         for (Batch &b : ctx->batches) {
+            if (b.kind == ADMM_KIND_GENERIC) {      // user rows: u, z live on the host; the dual residual goes through the same slots with w^2 coefficients
+                std::vector<double> coef(b.g_sval.size());
+                for (size_t i = 0; i < coef.size(); ++i) { const double w = b.g_roww[b.g_srow_b[i]]; coef[i] = b.g_sval[i] * (w * w); }
+                TRY(upload(ctx, &b.d_g_scoef_res, coef));
+                slots += b.g_lslots;
+                continue;
+            }
             const int rows = ADMM_KIND_ROWS[b.kind], nl = std::max(b.n_local, 1);
             TRY(dalloc(ctx, &b.d_u_prev, (size_t)rows * nl)); TRY(dalloc(ctx, &b.d_z_prev, (size_t)rows * nl));
             TRY(upload(ctx, &b.d_G, b.G));
             slots += (int64_t)b.n_local * ADMM_KIND_NODES[b.kind]; maxn = std::max(maxn, b.n_local);
+        }
+        if (ctx->n_gen_rows) {
+            ctx->h_gen_u_prev.assign((size_t)ctx->n_gen_rows, 0.0); ctx->h_gen_z_prev.assign((size_t)ctx->n_gen_rows, 0.0);
+            TRY(dalloc(ctx, &ctx->d_gen_q2, (size_t)ctx->n_gen_rows)); TRY(dalloc(ctx, &ctx->d_gen_r2, 1));
         }
         slots = std::max<int64_t>(slots, ctx->n_fslots);      // same layout as the RHS slots
         TRY(dalloc(ctx, &ctx->d_res_slots, 3 * (size_t)std::max<int64_t>(slots, 1)));
@@ -989,8 +1000,12 @@ int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
 }
 // before the local step: keep u and z of the previous iteration
 int residual_snapshot(admm_hip_ctx *ctx, bool first_iteration) {
+    if (ctx->n_gen_rows) {      // user rows (host): at a frame's first iteration h_gen_z already holds D * m_x (admm_hip_step)
+        std::memcpy(ctx->h_gen_u_prev.data(), ctx->h_gen_u, sizeof(double) * (size_t)ctx->n_gen_rows);
+        std::memcpy(ctx->h_gen_z_prev.data(), ctx->h_gen_z, sizeof(double) * (size_t)ctx->n_gen_rows);
+    }
     for (Batch &b : ctx->batches) {
-        if (!b.n_local) continue;
+        if (!b.n_local || b.kind == ADMM_KIND_GENERIC) continue;
         const int rows = ADMM_KIND_ROWS[b.kind];
         const size_t bytes = sizeof(double) * (size_t)rows * b.n_local;
         HIPCHK(hipMemcpyAsync(b.d_u_prev, b.d_u, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1007,8 +1022,26 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     const int n3 = 3 * ctx->n_nodes;
     double *r2 = ctx->d_res + 2 * (size_t)it, *s2 = r2 + 1;
     bool first = true;
+    if (ctx->n_gen_rows) {      // user rows: |r|^2 of this rank's rows on the host, z - z_prev to the device for the dual residual
+        double r2h = 0.0;
+        for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC)
+            for (int el = 0; el < b.n_local; ++el) for (int64_t r = b.g_elem_row[b.local[el]]; r < b.g_elem_row[b.local[el] + 1]; ++r) {
+                const double d = ctx->h_gen_u[b.g_row0 + r] - ctx->h_gen_u_prev[b.g_row0 + r], w = b.g_roww[r];
+                r2h += (w * w) * (d * d);
+            }
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // h_gen_q may still be the source of generic_finish's asynchronous upload
+        for (int64_t r = 0; r < ctx->n_gen_rows; ++r) ctx->h_gen_q[r] = ctx->h_gen_z[r] - ctx->h_gen_z_prev[r];
+        HIPCHK(hipMemcpyAsync(ctx->d_gen_q2, ctx->h_gen_q, sizeof(double) * (size_t)ctx->n_gen_rows, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_gen_r2, &r2h, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // (r2h is a stack variable)
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, 1, (const double *)ctx->d_gen_r2, r2, 0);
+        first = false;
+        for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC && b.g_lslots)
+            hipLaunchKernelGGL(generic_rhs_kernel, dim3((3 * b.g_lslots + 255) / 256), dim3(256), 0, ctx->stream, 3 * b.g_lslots, (const int *)b.d_g_sptr, (const int *)b.d_g_srow,
+                               (const double *)b.d_g_scoef_res, (const int *)b.d_g_sdst, (const double *)ctx->d_gen_q2, ctx->d_res_slots);
+    }
     for (Batch &b : ctx->batches) {
-        if (!b.n_local) continue;
+        if (!b.n_local || b.kind == ADMM_KIND_GENERIC) continue;
         const int nb = (b.n_local + RES_BLOCK - 1) / RES_BLOCK, rows = ADMM_KIND_ROWS[b.kind];
         hipLaunchKernelGGL(residual_primal_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, b.n_local, rows, b.d_u, b.d_u_prev, b.d_w2, ctx->d_res_partial);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, r2, first ? 0 : 1);
@@ -1353,6 +1386,10 @@ int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
                 std::vector<double> coef(b.g_sval.size());
                 for (size_t i = 0; i < coef.size(); ++i) { const double w = b.g_roww[b.g_srow_b[i]]; coef[i] = b.g_sval[i] * ((ctx->dt * ctx->dt) * (w * w)); }
                 if (!coef.empty()) HIPCHK(hipMemcpy(b.d_g_scoef, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+                if (b.d_g_scoef_res && !coef.empty()) {
+                    for (size_t i = 0; i < coef.size(); ++i) { const double w = b.g_roww[b.g_srow_b[i]]; coef[i] = b.g_sval[i] * (w * w); }
+                    HIPCHK(hipMemcpy(b.d_g_scoef_res, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+                }
                 continue;
             }
             const int nl = b.n_local;

@@ -92,7 +92,7 @@ int admm_hip_add_batch(admm_hip_ctx *ctx, int kind, int n_elems, const int32_t *
  * (generic batches concatenated in add order: a force's offset is the `weights.size()` it saw in
  * get_selector when only user forces push weights); it must update u and z of this rank's elements
  * (admm_hip_local_elements) and leave the rest alone.  u starts at 0 and persists; z is D*m_x at the
- * start of every frame (System.cpp:43).  No HIP graph, no residual tracking with generic batches.   */
+ * start of every frame (System.cpp:43).  No HIP graph with generic batches (host code inside the iteration).   */
 typedef int (*admm_hip_project_fn)(void *user, double dt, int64_t n_rows, const double *Dx, double *u, double *z);
 int admm_hip_add_generic_batch(admm_hip_ctx *ctx, int n_elems, const int32_t *elem_row_ptr, int64_t n_triplets,
                                const int32_t *trip_row, const int32_t *trip_col, const double *trip_val,

@@ -451,3 +451,32 @@ def test_user_forces_sharded(pkg, monkeypatch, world, mode):
         for f in range(3):
             assert np.abs(xs[f] - refx[f]).max() < 1e-9, (r, f)
         assert np.array_equal(xs[-1], out[0][1][-1]) and np.array_equal(vs, out[0][2])
+
+
+@pytest.mark.gpu
+def test_user_forces_residuals_match_builtin(pkg, monkeypatch):
+    """Residual tracking with user-defined forces: |r| and |s| per ADMM iteration of the user-spring net equal those of the built-in
+    spring kernel (the user rows' |r|^2 is summed on the host, their share of s goes through the same slots), and the early exit
+    stops at the same iteration."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    x, pairs = _spring_net(11)
+    k = 400.0
+    res = []
+    for generic in (False, True):
+        s = _user_spring_system(pkg, x, pairs, k, generic=generic)
+        s.initialize(); s.enable_residuals(True)
+        s.step(12)
+        r, sd, n = s.residuals()
+        assert n == 12 and r.size == 12
+        res.append((r.copy(), sd.copy(), s.m_x.copy()))
+    assert np.array_equal(res[0][2], res[1][2])
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=1e-14) and np.allclose(res[0][1], res[1][1], rtol=1e-10, atol=1e-14)
+    assert res[0][0][-1] < res[0][0][0]                       # the primal residual falls over the frame
+    tol_r, tol_s = 1.5 * res[0][0][6], 1.5 * res[0][1][6]
+    stops = []
+    for generic in (False, True):
+        s = _user_spring_system(pkg, x, pairs, k, generic=generic)
+        s.initialize(); s.set_tolerance(tol_r, tol_s, 1)
+        s.step(12)
+        stops.append(s.residuals()[2])
+    assert stops[0] == stops[1] and stops[0] < 12
