@@ -141,6 +141,7 @@ struct admm_hip_ctx {
     bool graph_enabled = true, graph_forced = false; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     int bwd_nw = 8, bwd_small_nw = 4;                               // backward sweep, levels of wide supernodes: waves (= columns) per block sharing one staging (ADMM_HIP_BWD_NW = 4 / 8 / 16)
+    int xcd_min_supernodes = 16;                  // levels with at least this many supernodes get the XCD-aware item order (0 = off; ADMM_HIP_XCD)
     int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
     int fwd_nw4_kmax = 200, fwd_nw8_kmax = 400;   // forward sweep: levels whose widest supernode has at most this many columns run 4 / 8 waves per tile (ADMM_HIP_FWD_NW4 / _NW8)
     bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
@@ -508,6 +509,36 @@ void assign_elements(admm_hip_ctx *ctx) {
     ctx->info.n_elems_local = nloc;
 }
 
+// XCD-aware order of a level's work items.  Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i mod 8), each
+// with its own L2: in plain order the tiles of ONE supernode land on all eight, and every L2 fetches that supernode's staged
+// vector (y, contribution lists, the children's contributions / x of its rows) from HBM again.  Here every supernode of a level
+// is given to one XCD (longest first onto the least loaded) and the list is interleaved so that its items get workgroup ids of
+// that XCD; queues of unequal length are padded with empty items (k = r = 0: the kernels do nothing for them).  `group` = items
+// per workgroup (the wave-per-tile forward kernel packs several).  Levels with few supernodes keep the plain order: there every
+// XCD is needed for each of them.
+void xcd_order(std::vector<admm_dev::SweepItem> &items, int group, int min_supernodes) {
+    const int NX = 8;
+    std::vector<std::pair<int, int> > runs;      // (first item, count) per supernode; a supernode's items are consecutive
+    for (size_t i = 0; i < items.size();) { size_t j = i; while (j < items.size() && items[j].s == items[i].s) ++j; runs.push_back({(int)i, (int)(j - i)}); i = j; }
+    if ((int)runs.size() < min_supernodes) return;
+    std::vector<int> ord(runs.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return runs[a].second > runs[b].second; });
+    std::vector<std::vector<admm_dev::SweepItem> > q(NX);
+    for (int r : ord) {
+        int best = 0;
+        for (int x = 1; x < NX; ++x) if (q[x].size() < q[best].size()) best = x;
+        q[best].insert(q[best].end(), items.begin() + runs[r].first, items.begin() + runs[r].first + runs[r].second);
+    }
+    size_t len = 0;
+    for (int x = 0; x < NX; ++x) len = std::max(len, (q[x].size() + group - 1) / group * group);
+    admm_dev::SweepItem none{};
+    std::vector<admm_dev::SweepItem> out;
+    out.reserve(len * NX);
+    for (size_t g0 = 0; g0 < len; g0 += group) for (int x = 0; x < NX; ++x) for (int t = 0; t < group; ++t) out.push_back(g0 + t < q[x].size() ? q[x][g0 + t] : none);
+    items.swap(out);
+}
+
 // ---- device upload ----------------------------------------------------------
 template <class T> std::vector<T> permute_nodes(const std::vector<T> &h, const std::vector<int> &perm, int comps) {
     std::vector<T> o(h.size());
@@ -569,6 +600,7 @@ int upload_factor(admm_hip_ctx *ctx) {
                 const int chunks = (S.ncols + L.bwd_nw * L.bwd_cw - 1) / (L.bwd_nw * L.bwd_cw);
                 for (int c = 0; c < chunks; ++c) { it.part = c; bw.push_back(it); }
             }
+            if (ctx->xcd_min_supernodes > 0) { xcd_order(sm, ADMM_FWD_SMALL_WAVES, ctx->xcd_min_supernodes); xcd_order(bg, 1, ctx->xcd_min_supernodes); xcd_order(bw, 1, ctx->xcd_min_supernodes); }
             L.n_small = (int)sm.size(); L.n_big = (int)bg.size(); L.n_bwd = (int)bw.size();
             {
                 int kmax = 0;
@@ -1101,6 +1133,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
+    if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW4")) ctx->fwd_nw4_kmax = atoi(g);
