@@ -849,6 +849,15 @@ FactorDev factor_dev(const admm_hip_ctx *ctx) {
 int max_lbfgs_iters(const Batch &b) { return b.max_iter; }
 
 // local step: every batch kernel on x_cur
+#ifdef ADMM_TET_PROFILE
+// tools/probe/ls_predict_gpu.py only (variant build): per-tet trace of the next `cap` launches of the tet kernel
+float *g_trace_base; int g_trace_cap, g_trace_n, g_trace_count;
+void tet_trace_next(hipStream_t st) {
+    float *p = (g_trace_base && g_trace_count < g_trace_cap) ? g_trace_base + 2 * (size_t)g_trace_count * g_trace_n : nullptr;
+    ++g_trace_count;
+    hipMemcpyToSymbolAsync(HIP_SYMBOL(admm_dev::g_tet_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, st);
+}
+#endif
 int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
     using namespace admm_dev;
     for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
@@ -860,6 +869,9 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
         const double *x = ctx->d_xcur;
         switch (b.kind) {
         case ADMM_KIND_TET_NH:
+#ifdef ADMM_TET_PROFILE
+            tet_trace_next(ctx->stream);
+#endif
             if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, ctx->stream, d, x);
             else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, ctx->stream, d, x);
             break;
@@ -1320,6 +1332,17 @@ int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
     return ADMM_OK;
 }
 #ifdef ADMM_TET_PROFILE
+// tools/probe/ls_predict_gpu.py only (variant build): per-tet trace of the next `cap` launches of the tet kernel (0: off)
+extern "C" int admm_hip_debug_tet_trace(int cap, int n) {
+    hipFree(g_trace_base); g_trace_base = nullptr; g_trace_cap = cap; g_trace_n = n; g_trace_count = 0;
+    if (cap > 0 && hipMalloc(&g_trace_base, sizeof(float) * 2 * (size_t)cap * n) != hipSuccess) return ADMM_ERR_HIP;
+    return ADMM_OK;
+}
+extern "C" int admm_hip_debug_tet_trace_read(float *out) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, g_trace_base, sizeof(float) * 2 * (size_t)g_trace_cap * g_trace_n, hipMemcpyDeviceToHost) != hipSuccess) return ADMM_ERR_HIP;
+    g_trace_count = 0;
+    return ADMM_OK;
+}
 // tools/tet_phase_profile.py only (variant build): read and clear the tet kernel's phase counters
 extern "C" int admm_hip_debug_tet_profile(unsigned long long *out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 96) != hipSuccess) return ADMM_ERR_HIP;

@@ -34,6 +34,7 @@ namespace admm_dev {
 // shipped library): s_memtime deltas accumulated by lane 0 of every wave, per-lane loop counts as (sum, 64 x wave maximum)
 #if defined(ADMM_TET_PROFILE) && defined(__HIPCC__)
 __device__ unsigned long long g_tet_prof[96];   // [0..31] phase ticks / loop counts, [32..63] histogram of line-search evaluations per tet, [64..95] of the wave maxima
+__device__ float *g_tet_trace;                  // per tet of the current launch: [max |gradient| at the warm start, line-search evaluations] (tools/probe/ls_predict_gpu.py)
 #endif
 #if defined(ADMM_TET_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ unsigned long long prof_now() { return __builtin_readcyclecounter(); }
@@ -657,10 +658,14 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     V3 x2; x2.a = sa; x2.b = sb; x2.c = sc;
     if (x2.c < 0.0) x2.c *= -1.0;
     else if (fabs(x2.a) < 1.e-3 && fabs(x2.b) < 1.e-3 && fabs(x2.c) < 1.e-3) { x2.a = 1.e-3; x2.b = 1.e-3; x2.c = 1.e-3; }
+#if ADMM_PROF_ON
+    const double prof_g0 = absmax(P.gradient(x2));
+#endif
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
     sa = x2.a; sb = x2.b; sc = x2.c;
     ADMM_PROF_TIME(2);
 #if ADMM_PROF_ON
+    if (g_tet_trace) { float *t = g_tet_trace + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); t[0] = (float)prof_g0; t[1] = (float)P.prof_nfev; }
     ADMM_PROF_COUNT(12, n_iters); ADMM_PROF_COUNT(14, P.prof_nfev); ADMM_PROF_HIST(P.prof_nfev);
     const Mat3 zr = recompose(U, x2.a, x2.b, x2.c, V);
     ADMM_PROF_TIME(3);

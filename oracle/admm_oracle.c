@@ -743,6 +743,13 @@ static void recompose3(const double *U, const double *s, const double *Vt, doubl
         M3(out, i, j) = ((M3(U, i, 0) * s[0]) * M3(Vt, 0, j) + (M3(U, i, 1) * s[1]) * M3(Vt, 1, j)) + (M3(U, i, 2) * s[2]) * M3(Vt, 2, j);
 }
 
+#ifdef ORC_LS_TRACE
+/* probe only (tools/probe/ls_predict.py): per tet [max|g0|, f0, evaluations, outer iterations, x0 min, s0 min] of the last project() */
+static double *orc_ls_trace_buf;
+static size_t orc_ls_trace_stride;      /* doubles per ADMM iteration (0: every iteration overwrites the last) */
+static int orc_ls_trace_it;
+void orc_set_ls_trace(double *buf, size_t stride) { orc_ls_trace_buf = buf; orc_ls_trace_stride = stride; }
+#endif
 /* HyperElasticTet::project, CORE/TetForce.cpp:320-364 */
 static void project_hyper(orc_force *f, const double *Dx, double *u, double *z) {
     double F[9];
@@ -756,8 +763,19 @@ static void project_hyper(orc_force *f, const double *Dx, double *u, double *z) 
     double x2[3] = { f->state[0], f->state[1], f->state[2] };
     if (x2[2] < 0.0) x2[2] *= -1.0;
     else if (fabs(x2[0]) < 1.e-3 && fabs(x2[1]) < 1.e-3 && fabs(x2[2]) < 1.e-3) { x2[0] = 1.e-3; x2[1] = 1.e-3; x2[2] = 1.e-3; }
+#ifdef ORC_LS_TRACE
+    double tr_g[3], tr_f = prox_value(&P, x2), tr_x = STD_MIN(x2[0], STD_MIN(x2[1], x2[2]));
+    prox_gradient(&P, x2, tr_g);
+    P.n_fev = 0;
+#endif
     f->n_iters = lbfgs_minimize(&P, x2, (int)f->params[2], 1e-8, &f->state[3]);
     f->n_fev = P.n_fev;
+#ifdef ORC_LS_TRACE
+    if (orc_ls_trace_buf) {
+        double *t = orc_ls_trace_buf + orc_ls_trace_stride * orc_ls_trace_it + 6 * (size_t)(f->global_idx / 9);
+        t[0] = absmaxn(tr_g, 3); t[1] = tr_f; t[2] = P.n_fev; t[3] = f->n_iters; t[4] = tr_x; t[5] = STD_MIN(S0[0], STD_MIN(S0[1], S0[2]));
+    }
+#endif
     f->state[0] = x2[0]; f->state[1] = x2[1]; f->state[2] = x2[2];
     double zi[9];
     recompose3(U, x2, Vt, zi);
@@ -1271,6 +1289,9 @@ int orc_step(orc_system *s) {
     if (s->track_res) { zprev = (double *)malloc(sizeof(double) * R); sv = (double *)malloc(sizeof(double) * n); }
     s->res_n = 0;
     for (int it = 0; it < s->admm_iters; ++it) {
+#ifdef ORC_LS_TRACE
+        orc_ls_trace_it = it;
+#endif
         if (s->track_res) memcpy(zprev, s->z, sizeof(double) * R);
         spmv_D(s, s->xc, s->Dx);                            /* Dx = D*curr_x           :54 */
 #pragma omp parallel for schedule(static)
