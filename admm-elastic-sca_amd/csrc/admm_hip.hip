@@ -86,6 +86,7 @@ struct LevelDev {
     struct Root { int k, first; int64_t foff, inv_off; };
     std::vector<Root> roots;                                   // roots solved with their explicit inverse: gather + one row-wise product (no backward items)
     int n_bwd = 0, bwd_cw = 1, bwd_nw = 4; admm_dev::SweepItem *d_bwd = nullptr;   // backward: columns per wave, waves per block
+    int level = 0; double mbytes = 0.0;                        // diagnostics: position in the tree, panel bytes of this level's supernodes
 };
 
 } // namespace
@@ -126,6 +127,14 @@ struct admm_hip_ctx {
     int shard_mode = 0;                       // 0: contiguous element ranges + replicated solve, 1: subtrees
     std::vector<int> sn_owner, node_owner;    // -1 = top (replicated); node_owner in factor order
     std::vector<LevelDev> levels_top;         // sweep items of the top supernodes (levels = this rank's own ones)
+    // Concurrent subtree groups on ONE GPU (ADMM_HIP_GROUPS, not with subtree sharding): the elimination tree below a small top is
+    // cut into `groups` sets of independent subtrees; group 0 runs on the context's stream (levels), the others on side streams
+    // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
+    int groups = 1;
+    std::vector<int> grp_owner;               // per supernode: group, -1 = top
+    std::vector<std::vector<LevelDev> > levels_side;
+    std::vector<LevelDev> levels_gtop;
+    std::vector<hipStream_t> side_streams; hipEvent_t ev_fork = nullptr; std::vector<hipEvent_t> ev_join;
     int n_comm_top = 0, n_comm_slots = 0;
     int *d_comm_top = nullptr, *d_comm_slots = nullptr; unsigned char *d_comm_mine = nullptr, *d_base_mask = nullptr, *d_keep_mask = nullptr;
     double *d_comm_buf = nullptr;
@@ -243,7 +252,7 @@ void free_device(admm_hip_ctx *ctx) {
     if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
-    ctx->levels.clear();
+    ctx->levels.clear(); ctx->levels_side.clear(); ctx->levels_gtop.clear();
 }
 
 // scalar "G" matrix of an element: nodes x cols, so that K_e = dt^2 w^2 G G^T
@@ -431,11 +440,10 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
 // Split the heaviest open subtree at its root (the root joins the replicated top) until there are >= 4 open subtrees per
 // rank, then give the subtrees to the ranks largest first (LPT).  Every vertex separator is a supernode, so an element
 // whose nodes are not all in the top lies inside exactly ONE subtree plus its ancestors: it goes to that subtree's rank.
-void partition_subtrees(admm_hip_ctx *ctx) {
-    const Factor &F = ctx->F;
-    const int ns = (int)F.sn.size(), world = ctx->world;
-    ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
-    if (ctx->shard_mode != 1 || world <= 1) return;
+// `owner` <- part of every supernode (-1 = top) for `parts` parts; returns the loads through `load`, counts through n_top / n_sub
+void subtree_owners(const Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub) {
+    const int ns = (int)F.sn.size(), world = parts;
+    owner.assign(ns, 0);
     std::vector<double> weight(ns, 0.0);
     std::vector<std::vector<int> > kids(ns);
     for (int s = 0; s < ns; ++s) {   // postorder: children come before parents
@@ -448,7 +456,7 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     for (int s = 0; s < ns; ++s) if (F.sn[s].parent < 0) open.push_back(s);
     std::make_heap(open.begin(), open.end(), cmp);
     // LPT assignment of the current subtrees; returns max load / mean load
-    std::vector<double> load(world, 0.0);
+    load.assign(world, 0.0);
     std::vector<int> root_owner(ns, -2);
     auto assign = [&]() {
         std::vector<int> all(done); all.insert(all.end(), open.begin(), open.end());
@@ -472,14 +480,34 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     assign();
     done.insert(done.end(), open.begin(), open.end());
     for (int s = ns - 1; s >= 0; --s) {   // parents before children
-        if (top[s]) ctx->sn_owner[s] = -1;
-        else if (root_owner[s] != -2) ctx->sn_owner[s] = root_owner[s];
-        else ctx->sn_owner[s] = ctx->sn_owner[F.sn[s].parent];
+        if (top[s]) owner[s] = -1;
+        else if (root_owner[s] != -2) owner[s] = root_owner[s];
+        else owner[s] = owner[F.sn[s].parent];
     }
+    n_top = 0; for (int s = 0; s < ns; ++s) n_top += top[s];
+    n_sub = done.size();
+}
+
+void partition_subtrees(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size(), world = ctx->world;
+    ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
+    ctx->grp_owner.clear();
+    if (!(ctx->shard_mode == 1 && world > 1) && ctx->groups > 1 && !ctx->dense) {      // concurrent groups on this GPU
+        std::vector<double> load; int nt = 0; size_t nsub = 0;
+        subtree_owners(F, ctx->groups, ctx->grp_owner, load, nt, nsub);
+        if (getenv("ADMM_HIP_VERBOSE")) {
+            fprintf(stderr, "admm_hip: %d concurrent subtree groups: %d top supernodes, %zu subtrees, load per group (1e6 entries):", ctx->groups, nt, nsub);
+            for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
+            fprintf(stderr, "\n");
+        }
+    }
+    if (ctx->shard_mode != 1 || world <= 1) return;
+    std::vector<double> load; int nt = 0; size_t nsub = 0;
+    subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
     for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];
     if (getenv("ADMM_HIP_VERBOSE")) {
-        int nt = 0; for (int s = 0; s < ns; ++s) nt += top[s];
-        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (1e6 entries):", nt, done.size());
+        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (1e6 entries):", nt, nsub);
         for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
         fprintf(stderr, "\n");
     }
@@ -546,7 +574,15 @@ template <class T> std::vector<T> permute_nodes(const std::vector<T> &h, const s
     return o;
 }
 
+#ifdef ADMM_SWEEP_PROFILE
+// tools/sweep_timeline.py only (variant build): every workgroup of every sweep launch owns a slot of one stamp buffer (the stamps
+// of the LAST iteration stay); meta: (tag, level, workgroups, KB, list, first slot) per launch
+unsigned long long *g_swp_base; size_t g_swp_wgs; std::vector<int> g_swp_meta;
+#endif
 int upload_factor(admm_hip_ctx *ctx) {
+#ifdef ADMM_SWEEP_PROFILE
+    g_swp_wgs = 0; g_swp_meta.clear();
+#endif
     Factor &F = ctx->F;
     const int ns = (int)F.sn.size();
     std::vector<int> first(ns), ncols(ns), nrows(ns);
@@ -573,25 +609,46 @@ int upload_factor(admm_hip_ctx *ctx) {
     const int fwd_small_k = std::min(ctx->fwd_small_k, admm_dev::FWD_SMALL_KMAX);
     const bool subtree = ctx->shard_mode == 1 && ctx->world > 1;
     ctx->levels_top.assign(subtree ? F.levels.size() : 0, LevelDev());
-    for (int pass = 0; pass < (subtree ? 2 : 1); ++pass) {      // pass 0: this rank's supernodes (all of them without subtree sharding), pass 1: the replicated top
+    const bool grouped = !subtree && !ctx->grp_owner.empty();
+    if (grouped) {
+        while ((int)ctx->side_streams.size() < ctx->groups - 1) {
+            hipStream_t st; hipEvent_t e;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); ctx->side_streams.push_back(st);
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_join.push_back(e);
+        }
+        if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    }
+    ctx->levels_side.assign(grouped ? ctx->groups - 1 : 0, std::vector<LevelDev>(F.levels.size()));
+    ctx->levels_gtop.assign(grouped ? F.levels.size() : 0, LevelDev());
+    // passes: (which supernodes, into which list).  Plain: all -> levels.  Subtree sharding: this rank's -> levels, the replicated
+    // top -> levels_top.  Concurrent groups: group 0 -> levels, group g -> levels_side[g - 1], the top -> levels_gtop.
+    struct Pass { int want; std::vector<LevelDev> *into; };
+    std::vector<Pass> passes;
+    if (subtree) { passes.push_back({ctx->rank, &ctx->levels}); passes.push_back({-1, &ctx->levels_top}); }
+    else if (grouped) { passes.push_back({0, &ctx->levels}); for (int g = 1; g < ctx->groups; ++g) passes.push_back({g, &ctx->levels_side[g - 1]}); passes.push_back({-1, &ctx->levels_gtop}); }
+    else passes.push_back({0, &ctx->levels});
+    const std::vector<int> *own = subtree ? &ctx->sn_owner : (grouped ? &ctx->grp_owner : nullptr);
+    for (const Pass &ps : passes) {
         for (size_t l = 0; l < F.levels.size(); ++l) {
-            LevelDev &L = pass == 0 ? ctx->levels[l] : ctx->levels_top[l];
+            LevelDev &L = (*ps.into)[l];
             std::vector<admm_dev::SweepItem> sm, bg, bw;
+            L.level = (int)l; L.mbytes = 0.0;
             const bool fwd_small = level_kmax[l] <= fwd_small_k, bwd_small = level_kmax[l] <= ctx->bwd_small_k;
             L.bwd_cw = bwd_small ? 4 : ADMM_BWD_BIG_CW;   // columns per wave in the backward kernel
             // eight columns per block pay where a level has thousands of columns (one staging of the vector per 8 instead of 4
             // columns); on levels with few columns the larger number of blocks matters more (50k-tet bar: 4 waves 222 us / 8: 228)
             int level_cols = 0;
-            for (int s : F.levels[l]) if (!subtree || ctx->sn_owner[s] == (pass == 0 ? ctx->rank : -1)) level_cols += F.sn[s].ncols;
+            for (int s : F.levels[l]) if (!own || (*own)[s] == ps.want) level_cols += F.sn[s].ncols;
             L.bwd_nw = bwd_small ? ctx->bwd_small_nw : (level_cols >= ctx->bwd_nw_min_cols ? ctx->bwd_nw : 4);
             for (int s : F.levels[l]) {
-                if (subtree && ctx->sn_owner[s] != (pass == 0 ? ctx->rank : -1)) continue;
+                if (own && (*own)[s] != ps.want) continue;
                 const Supernode &S = F.sn[s];
                 admm_dev::SweepItem it{};
                 it.s = s; it.k = S.ncols; it.r = S.nrows; it.first = S.first;
                 it.panel_off = S.panel_off; it.front_off = S.front_off; it.slot_off = S.slot_off; it.rows_off = S.rows_off;
                 const int f = S.ncols + S.nrows;
                 const int tiles = (f + 63) / 64;
+                L.mbytes += 8e-6 * ((double)f * S.ncols - 0.5 * (double)S.ncols * (S.ncols - 1));
                 if (S.root_inv_off >= 0 && ctx->root_inverse) {      // a root: x = (L L^T)^-1 t in the forward sweep, nothing in the backward sweep
                     L.roots.push_back({S.ncols, S.first, S.front_off, S.root_inv_off});
                     continue;
@@ -608,9 +665,31 @@ int upload_factor(admm_hip_ctx *ctx) {
                 // few tiles (all resident at once even with 16 waves each): the more waves share a tile's columns the shorter its chain
                 L.big_nw = (int)bg.size() <= ctx->fwd_nw16_max_tiles ? 16 : (kmax <= ctx->fwd_nw4_kmax ? 4 : (kmax <= ctx->fwd_nw8_kmax ? 8 : 16));
             }
+#ifdef ADMM_SWEEP_PROFILE
+            {
+                const int list = ps.want < 0 ? 100 : (&ps - &passes[0]);
+                auto reg = [&](std::vector<admm_dev::SweepItem> &v, int group, int tag) {
+                    if (v.empty()) return;
+                    const int n_wg = ((int)v.size() + group - 1) / group;
+                    for (size_t i = 0; i < v.size(); ++i) v[i].pad2 = (v[i].k || v[i].r) ? (long long)(g_swp_wgs + i / group) : -1;
+                    for (int q : {tag, (int)l, n_wg, (int)(L.mbytes * 1024), list, (int)g_swp_wgs}) g_swp_meta.push_back(q);
+                    g_swp_wgs += n_wg;
+                };
+                reg(sm, ADMM_FWD_SMALL_WAVES, 0); reg(bg, 1, L.big_nw); reg(bw, 1, 100 + 10 * L.bwd_cw + (L.bwd_nw == 16 ? 6 : L.bwd_nw));
+            }
+#endif
             TRY(upload(ctx, &L.d_small, sm)); TRY(upload(ctx, &L.d_big, bg)); TRY(upload(ctx, &L.d_bwd, bw));
         }
     }
+#ifdef ADMM_SWEEP_PROFILE
+    {
+        unsigned long long *p = nullptr;
+        TRY(dalloc(ctx, (double **)&p, 4 * g_swp_wgs + 4));
+        HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * (4 * g_swp_wgs + 4)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_sweep_prof), &p, sizeof(p)));
+        g_swp_base = p;
+    }
+#endif
     // subtree sharding: the exchange lists (see shard_pack_kernel) and the node masks
     ctx->n_comm_top = ctx->n_comm_slots = 0;
     ctx->d_comm_top = ctx->d_comm_slots = nullptr; ctx->d_comm_mine = ctx->d_base_mask = ctx->d_keep_mask = nullptr; ctx->d_comm_buf = nullptr;
@@ -940,40 +1019,56 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
         return ADMM_OK;
     }
     const FactorDev F = factor_dev(ctx);
-    auto forward = [&](const std::vector<LevelDev> &levels) {
+    auto forward = [&](const std::vector<LevelDev> &levels, hipStream_t st) {
         for (const LevelDev &L : levels) {
             if (L.n_small) {
-                if (F.cg4) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
-                else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, ctx->stream, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                                if (F.cg4) hipLaunchKernelGGL((solve_fwd_small_kernel<true>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, st, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
+                else hipLaunchKernelGGL((solve_fwd_small_kernel<false>), dim3((L.n_small + ADMM_FWD_SMALL_WAVES - 1) / ADMM_FWD_SMALL_WAVES), dim3(64 * ADMM_FWD_SMALL_WAVES), 0, st, L.n_small, L.d_small, F, ctx->d_y, ctx->d_w, ctx->d_c);
             }
             if (L.n_big) {
-#define ADMM_FWD_BIG(CG, NW) hipLaunchKernelGGL((solve_fwd_big_kernel<CG, NW>), dim3(L.n_big), dim3(64 * NW), 0, ctx->stream, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c)
+#define ADMM_FWD_BIG(CG, NW) hipLaunchKernelGGL((solve_fwd_big_kernel<CG, NW>), dim3(L.n_big), dim3(64 * NW), 0, st, L.d_big, F, ctx->d_y, ctx->d_w, ctx->d_c)
                 if (F.cg4) { if (L.big_nw == 4) ADMM_FWD_BIG(true, 4); else if (L.big_nw == 8) ADMM_FWD_BIG(true, 8); else ADMM_FWD_BIG(true, 16); }
                 else { if (L.big_nw == 4) ADMM_FWD_BIG(false, 4); else if (L.big_nw == 8) ADMM_FWD_BIG(false, 8); else ADMM_FWD_BIG(false, 16); }
 #undef ADMM_FWD_BIG
             }
             for (const LevelDev::Root &R : L.roots) {      // roots: both sweeps as one product with the explicit inverse, straight into x
                 double *T = ctx->d_w + 3 * (size_t)R.first;      // the root's own slice of W is free: it has no backward launch
-                if (F.cg4) hipLaunchKernelGGL((root_gather_kernel<true>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
-                else hipLaunchKernelGGL((root_gather_kernel<false>), dim3((R.k + 255) / 256), dim3(256), 0, ctx->stream, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
-                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + ROOT_ROWS - 1) / ROOT_ROWS), dim3(64 * ROOT_ROWS), 0, ctx->stream, R.k, root_inv_ld(R.k), (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
+                if (F.cg4) hipLaunchKernelGGL((root_gather_kernel<true>), dim3((R.k + 255) / 256), dim3(256), 0, st, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
+                else hipLaunchKernelGGL((root_gather_kernel<false>), dim3((R.k + 255) / 256), dim3(256), 0, st, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
+                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + ROOT_ROWS - 1) / ROOT_ROWS), dim3(64 * ROOT_ROWS), 0, st, R.k, root_inv_ld(R.k), (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
             }
         }
     };
-    auto backward = [&](const std::vector<LevelDev> &levels) {
+    auto backward = [&](const std::vector<LevelDev> &levels, hipStream_t st) {
         for (int l = (int)levels.size() - 1; l >= 0; --l) {
             const LevelDev &L = levels[l];
             if (!L.n_bwd) continue;
-            if (L.bwd_cw == 4 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<4, 8>), dim3(L.n_bwd), dim3(512), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 4 && L.bwd_nw == 2) hipLaunchKernelGGL((solve_bwd_kernel<4, 2>), dim3(L.n_bwd), dim3(128), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<1, 8>), dim3(L.n_bwd), dim3(512), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_nw == 16) hipLaunchKernelGGL((solve_bwd_kernel<1, 16>), dim3(L.n_bwd), dim3(1024), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, ctx->stream, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            if (L.bwd_cw == 4 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<4, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 4 && L.bwd_nw == 2) hipLaunchKernelGGL((solve_bwd_kernel<4, 2>), dim3(L.n_bwd), dim3(128), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<1, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_nw == 16) hipLaunchKernelGGL((solve_bwd_kernel<1, 16>), dim3(L.n_bwd), dim3(1024), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
         }
     };
-    forward(ctx->levels);
+    const int n_side = (int)ctx->levels_side.size();
+    // concurrent groups: the side streams start when the right-hand side is there and hand back before the top
+    auto fork = [&]() -> int {
+        if (!n_side) return ADMM_OK;
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int g = 0; g < n_side; ++g) HIPCHK(hipStreamWaitEvent(ctx->side_streams[g], ctx->ev_fork, 0));
+        return ADMM_OK;
+    };
+    auto join = [&]() -> int {
+        for (int g = 0; g < n_side; ++g) { HIPCHK(hipEventRecord(ctx->ev_join[g], ctx->side_streams[g])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g], 0)); }
+        return ADMM_OK;
+    };
+    TRY(fork());
+    for (int g = 0; g < n_side; ++g) forward(ctx->levels_side[g], ctx->side_streams[g]);
+    forward(ctx->levels, ctx->stream);
+    TRY(join());
+    if (n_side) forward(ctx->levels_gtop, ctx->stream);
     if (!ctx->levels_top.empty()) {
         // subtree sharding: own subtrees are done; ONE small all-reduce carries the top nodes' partial right-hand sides and the
         // subtree roots' contributions to every rank, then everybody runs the (replicated) top of the tree
@@ -987,11 +1082,15 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
                                (const int *)ctx->d_comm_slots, (const double *)ctx->d_comm_buf, ctx->d_y, ctx->d_c);
         }
         if (ex1) HIPCHK(hipEventRecord(ex1, ctx->stream));
-        forward(ctx->levels_top);
+        forward(ctx->levels_top, ctx->stream);
     }
     if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
-    if (!ctx->levels_top.empty()) backward(ctx->levels_top);
-    backward(ctx->levels);
+    if (!ctx->levels_top.empty()) backward(ctx->levels_top, ctx->stream);
+    if (n_side) backward(ctx->levels_gtop, ctx->stream);
+    TRY(fork());
+    for (int g = 0; g < n_side; ++g) backward(ctx->levels_side[g], ctx->side_streams[g]);
+    backward(ctx->levels, ctx->stream);
+    TRY(join());
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -1146,6 +1245,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW4")) ctx->fwd_nw4_kmax = atoi(g);
@@ -1166,6 +1266,9 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         if (ctx->rccl_comm && ctx->rccl_owned) { RcclApi *R = rccl_api(nullptr); if (R) (void)R->CommDestroy(ctx->rccl_comm); }
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
+        for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+        for (hipEvent_t e : ctx->ev_join) (void)hipEventDestroy(e);
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1331,6 +1434,15 @@ int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
     for (int i = 0; i < ctx->n_nodes; ++i) owner[i] = (ctx->shard_mode == ADMM_SHARD_SUBTREE && ctx->world > 1) ? ctx->node_owner[ctx->F.iperm[i]] : 0;
     return ADMM_OK;
 }
+#ifdef ADMM_SWEEP_PROFILE
+// -> stamps[4 * workgroups], meta[6 * launches]; returns the number of launches (negative: error; call with NULL for the sizes)
+extern "C" long admm_hip_debug_sweep_profile_read(unsigned long long *stamps, int *meta) {
+    if (!stamps) return (long)g_swp_wgs;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(stamps, g_swp_base, sizeof(unsigned long long) * 4 * g_swp_wgs, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (size_t i = 0; i < g_swp_meta.size(); ++i) meta[i] = g_swp_meta[i];
+    return (long)(g_swp_meta.size() / 6);
+}
+#endif
 #ifdef ADMM_TET_PROFILE
 // tools/probe/ls_predict_gpu.py only (variant build): per-tet trace of the next `cap` launches of the tet kernel (0: off)
 extern "C" int admm_hip_debug_tet_trace(int cap, int n) {

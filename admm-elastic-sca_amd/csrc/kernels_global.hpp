@@ -276,11 +276,23 @@ struct __attribute__((aligned(16))) SweepItem {
     int k, r;                    // columns, below-diagonal rows
     int first, pad;              // first column in factor order
     long long panel_off, front_off, slot_off, rows_off;
-    long long pad2;
+    long long pad2;              // (profile build -DADMM_SWEEP_PROFILE: the workgroup's slot in the stamp buffer, -1 = none)
 };
 static_assert(sizeof(SweepItem) == 64, "SweepItem is one 64-byte record");
 
 // sum of the children's contributions that land on front row `fr` (fixed child order)
+// ---- workgroup timeline of the sweep kernels (tools/sweep_timeline.py; variant build -DADMM_SWEEP_PROFILE, never on in the shipped
+// library): every workgroup stamps the 100 MHz real-time counter at its start, after its first staging barrier and at its end
+#if defined(ADMM_SWEEP_PROFILE) && defined(__HIPCC__)
+__device__ unsigned long long *g_sweep_prof;
+#define ADMM_SWEEP_T0 const unsigned long long swp_t0 = __builtin_amdgcn_s_memrealtime(); long long swp_slot = -1;
+#define ADMM_SWEEP_SLOT(v) do { swp_slot = (v); if (threadIdx.x == 0 && admm_dev::g_sweep_prof && swp_slot >= 0) admm_dev::g_sweep_prof[4 * swp_slot] = swp_t0; } while (0)
+#define ADMM_SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && admm_dev::g_sweep_prof && swp_slot >= 0) admm_dev::g_sweep_prof[4 * swp_slot + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ADMM_SWEEP_T0
+#define ADMM_SWEEP_SLOT(v)
+#define ADMM_SWEEP_STAMP(slot)
+#endif
 template <bool CG2>
 __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const double *__restrict__ C, double &s0, double &s1, double &s2) {
     s0 = 0.0; s1 = 0.0; s2 = 0.0;
@@ -327,9 +339,10 @@ __global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_ker
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = blockIdx.x * ADMM_FWD_SMALL_WAVES + wave;
     const bool live = item < n_items;
+    ADMM_SWEEP_T0
     int tile = 0, k = 0, r = 0, first = 0;
     int64_t foff = 0, poff = 0, soff = 0;
-    if (live) { const SweepItem it = items[item]; tile = it.part; k = it.k; r = it.r; first = it.first; foff = it.front_off; poff = it.panel_off; soff = it.slot_off; }
+    if (live) { const SweepItem it = items[item]; tile = it.part; k = it.k; r = it.r; first = it.first; foff = it.front_off; poff = it.panel_off; soff = it.slot_off; ADMM_SWEEP_SLOT(it.pad2); }
     const int f = k + r;
     const int i = tile * 64 + lane;
     const bool row_ok = live && i < f;
@@ -350,7 +363,8 @@ __global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_ker
         ts[wave][3 * lane] = src[0] - s0; ts[wave][3 * lane + 1] = src[1] - s1; ts[wave][3 * lane + 2] = src[2] - s2;
     }
     __syncthreads();
-    if (!row_ok) return;
+    ADMM_SWEEP_STAMP(1);
+    if (!row_ok) { ADMM_SWEEP_STAMP(2); return; }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int j = 0; j < jend; j += DS) {
 #pragma unroll
@@ -366,6 +380,7 @@ __global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_ker
         double *dst = C + 3 * (size_t)(soff + (i - k));
         dst[0] = a0 + c0; dst[1] = a1 + c1; dst[2] = a2 + c2;
     }
+    ADMM_SWEEP_STAMP(2);
 }
 
 // Forward sweep, supernodes with k > 64: one block of NW waves = one
@@ -382,7 +397,9 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
     __shared__ double ts[FWD_BIG_KCHUNK * 3];
     __shared__ double red[NW][64 * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ADMM_SWEEP_T0
     const SweepItem it = items[blockIdx.x];
+    ADMM_SWEEP_SLOT(it.pad2);
     const int tile = it.part, k = it.k, r = it.r, first = it.first;
     const int64_t foff = it.front_off;
     const int f = k + r;
@@ -432,6 +449,7 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
             ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
         }
         __syncthreads();
+        if (c0 == 0) ADMM_SWEEP_STAMP(1);
         for (int j = jb; j < je; j += D) {
 #pragma unroll
             for (int q = 0; q < D; ++q) nxt[q] = (j + D + q < je) ? P[(size_t)f * (j + D + q)] : 0.0;
@@ -455,6 +473,7 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
             else C[3 * (size_t)(it.slot_off + (row - k)) + c] = acc + carry;
         }
     }
+    ADMM_SWEEP_STAMP(2);
 }
 
 // Backward sweep: one 256-thread block = (supernode, 4*CW columns), each wave owns
@@ -498,7 +517,9 @@ __global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__
                                                         FactorDev F, const double *__restrict__ W, double *__restrict__ X) {
     __shared__ double vs[BWD_RCHUNK * 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ADMM_SWEEP_T0
     const SweepItem it = items[blockIdx.x];
+    ADMM_SWEEP_SLOT(it.pad2);
     const int chunk = it.part, k = it.k, r = it.r, first = it.first;
     const int f = k + r;
     const int *rows = F.rows + it.rows_off;
@@ -526,6 +547,7 @@ __global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__
             vs[3 * q] = v0; vs[3 * q + 1] = v1; vs[3 * q + 2] = v2;
         }
         __syncthreads();
+        if (r0 == jc0) ADMM_SWEEP_STAMP(1);
         if (j0 < k) {
             if (CW == 1) {
                 int q = lane;
@@ -568,6 +590,7 @@ __global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__
         const int c = base / 3, m = base - 3 * c;
         if (j0 + c < k) X[3 * (size_t)(first + j0 + c) + m] = v[0];
     }
+    ADMM_SWEEP_STAMP(2);
 }
 
 // Roots of the elimination tree: x_s = (L_ss L_ss^T)^-1 t_s, both sweeps in one product.  t_s = y_s - (children's contributions)
