@@ -17,6 +17,7 @@
 #include "factor.hpp"
 #include "force_init.hpp"
 #include "kernels_global.hpp"
+#include "factor_dev.hpp"
 #include "kernels_local.hpp"
 
 extern "C" int omp_get_max_threads(void);
@@ -130,6 +131,7 @@ struct admm_hip_ctx {
     // Concurrent subtree groups on ONE GPU (ADMM_HIP_GROUPS, not with subtree sharding): the elimination tree below a small top is
     // cut into `groups` sets of independent subtrees; group 0 runs on the context's stream (levels), the others on side streams
     // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
+    bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
     int groups = 1;
     std::vector<int> grp_owner;               // per supernode: group, -1 = top
     std::vector<std::vector<LevelDev> > levels_side;
@@ -397,11 +399,17 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         if (const char *e = getenv("ADMM_HIP_MERGE_ROOT")) merge_root = atoi(e) != 0;
         analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root);
     }
-    int err = factorize(ctx->A, ctx->F, threads);
-    if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
+    // numeric phase: on the device when there is one (device_factorize, from upload_factor / recompute_weights); the small-system
+    // inverse and device-less contexts (CPU tests of the host factorization) factor here
+    ctx->device_numeric = ctx->device_id >= 0 && ctx->device_factor && !(ctx->n_nodes > 0 && ctx->n_nodes <= ctx->dense_max);
     Factor &F = ctx->F;
+    if (ctx->device_numeric) { plan_panels(F); F.panels.clear(); F.t_numeric = 0.0; }
+    else {
+        int err = factorize(ctx->A, ctx->F, threads);
+        if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
+    }
     ctx->info.nnz_L = F.nnz_tri;
-    ctx->info.panel_bytes = (int64_t)F.panels.size() * 8;
+    ctx->info.panel_bytes = F.panels_size * 8;
     ctx->info.n_supernodes = (int64_t)F.sn.size();
     ctx->info.n_levels = (int64_t)F.levels.size();
     ctx->info.max_super_cols = F.max_cols; ctx->info.max_super_rows = F.max_rows;
@@ -433,6 +441,220 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) { const double a = 0.5 * (ctx->Ainv[(size_t)i * n + j] + ctx->Ainv[(size_t)j * n + i]); ctx->Ainv[(size_t)i * n + j] = a; ctx->Ainv[(size_t)j * n + i] = a; }
         ctx->info.t_numeric_s += now_s() - t0;
     }
+    return ADMM_OK;
+}
+
+// ---- numeric factorization on the device (factor_dev.hpp) -------------------------------------------------------------
+// The symbolic structure (ctx->F: supernodes, rows, levels) is the host's; this fills ctx->d_panels.  Every call builds the task
+// records against freshly allocated fronts (all fronts resident at once: sum f^2 doubles, 3.2 GB at the 1M-tet bar), runs the
+// launches level by level on the context's stream and frees the fronts again.  Returns ADMM_ERR_NOMEM_DEVICE_FACTOR (> 0, internal)
+// when the fronts do not fit: the caller then factors on the host as before.
+constexpr int ADMM_DEVFACTOR_NOFIT = 1000;
+int device_factorize(admm_hip_ctx *ctx) {
+    using namespace admm_dev;
+    const double t0 = now_s();
+    Factor &F = ctx->F;
+    const int ns = (int)F.sn.size();
+    std::vector<int64_t> foff(ns);
+    int64_t ftot = 0;
+    for (int s = 0; s < ns; ++s) { const int64_t f = F.sn[s].ncols + F.sn[s].nrows; foff[s] = ftot; ftot += f * f; }
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if ((double)ftot * 8.0 > 0.8 * (double)free_b) return ADMM_DEVFACTOR_NOFIT;
+    // original entries: destination in the fronts, source in A
+    SymCSC PA;
+    permuted_lower(ctx->A, F, PA, true);
+    const int64_t nnz = (int64_t)PA.idx.size();
+    std::vector<int64_t> adst(nnz); std::vector<int> asrc(nnz);
+    for (int s = 0; s < ns; ++s) {
+        const Supernode &S = F.sn[s];
+        const int k = S.ncols, f = k + S.nrows;
+        const int *rows = F.rows.data() + S.rows_off;
+        for (int j = 0; j < k; ++j) {
+            const int col = S.first + j;
+            for (int64_t p = PA.ptr[col]; p < PA.ptr[col + 1]; ++p) {
+                const int row = PA.idx[p];
+                const int loc = row < S.first + k ? row - S.first : k + (int)(std::lower_bound(rows, rows + S.nrows, row) - rows);
+                adst[p] = foff[s] + loc + (int64_t)f * j; asrc[p] = (int)PA.val[p];
+            }
+        }
+    }
+    // a child's update rows in its parent's front
+    std::vector<int> rel(std::max<size_t>(F.rows.size(), 1), 0);
+    std::vector<std::vector<int> > kids(ns);
+    for (int s = 0; s < ns; ++s) {
+        const Supernode &S = F.sn[s];
+        if (S.parent < 0) continue;
+        kids[S.parent].push_back(s);
+        const Supernode &Pn = F.sn[S.parent];
+        const int *prow = F.rows.data() + Pn.rows_off, *rows = F.rows.data() + S.rows_off;
+        for (int a = 0; a < S.nrows; ++a) {
+            const int row = rows[a];
+            rel[S.rows_off + a] = row < Pn.first + Pn.ncols ? row - Pn.first : Pn.ncols + (int)(std::lower_bound(prow, prow + Pn.nrows, row) - prow);
+        }
+    }
+    // device buffers of this call
+    double *d_fronts = nullptr, *d_aval = nullptr; int64_t *d_adst = nullptr; int *d_asrc = nullptr, *d_rel = nullptr, *d_fail = nullptr;
+    GemmTask *d_gemm = nullptr; PotrfTask *d_potrf = nullptr; ExtendTask *d_ext = nullptr;
+    auto cleanup = [&]() { for (void *p : {(void *)d_fronts, (void *)d_aval, (void *)d_adst, (void *)d_asrc, (void *)d_rel, (void *)d_fail, (void *)d_gemm, (void *)d_potrf, (void *)d_ext}) if (p) (void)hipFree(p); };
+    if (hipMalloc(&d_fronts, sizeof(double) * std::max<int64_t>(ftot, 1)) != hipSuccess) { (void)hipGetLastError(); return ADMM_DEVFACTOR_NOFIT; }
+#define DF_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(ctx, ADMM_ERR_HIP, "device factorization: %s: %s", #call, hipGetErrorString(e_)); } } while (0)
+    hipStream_t st = ctx->stream;
+    DF_CHK(hipMemsetAsync(d_fronts, 0, sizeof(double) * std::max<int64_t>(ftot, 1), st));
+    DF_CHK(hipMemsetAsync(ctx->d_panels, 0, sizeof(double) * std::max<int64_t>(F.panels_size, 1), st));
+    DF_CHK(hipMalloc(&d_aval, sizeof(double) * std::max<size_t>(ctx->A.val.size(), 1)));
+    DF_CHK(hipMalloc(&d_adst, sizeof(int64_t) * std::max<int64_t>(nnz, 1)));
+    DF_CHK(hipMalloc(&d_asrc, sizeof(int) * std::max<int64_t>(nnz, 1)));
+    DF_CHK(hipMalloc(&d_rel, sizeof(int) * rel.size()));
+    DF_CHK(hipMalloc(&d_fail, sizeof(int)));
+    DF_CHK(hipMemcpyAsync(d_aval, ctx->A.val.data(), sizeof(double) * ctx->A.val.size(), hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemcpyAsync(d_adst, adst.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemcpyAsync(d_asrc, asrc.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemcpyAsync(d_rel, rel.data(), sizeof(int) * rel.size(), hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    // task records and the launch sequence
+    std::vector<GemmTask> gemm; std::vector<PotrfTask> potrf; std::vector<ExtendTask> ext;
+    struct Launch { int kind, first, count, gx; };      // kind 0 extend-add, 1 potrf + block inverse, 2 gemm
+    std::vector<Launch> launches;
+    double *Pn = ctx->d_panels;
+    auto front = [&](int s) { return d_fronts + foff[s]; };
+    auto close_gemm = [&](size_t first) {
+        if (gemm.size() == first) return;
+        int gx = 1;
+        for (size_t q = first; q < gemm.size(); ++q) gx = std::max(gx, ((gemm[q].m + 63) / 64) * ((gemm[q].n + 63) / 64));
+        launches.push_back({2, (int)first, (int)(gemm.size() - first), gx});
+    };
+    auto add_gemm = [&](const double *A, int lda, const double *B, int ldb, double *C, int ldc, int m, int n, int k, int flags, double alpha, double beta) {
+        if (m <= 0 || n <= 0 || k <= 0) return;
+        GemmTask T{}; T.A = A; T.B = B; T.C = C; T.m = m; T.n = n; T.k = k; T.lda = lda; T.ldb = ldb; T.ldc = ldc; T.flags = flags; T.alpha = alpha; T.beta = beta;
+        gemm.push_back(T);
+    };
+    for (size_t l = 0; l < F.levels.size(); ++l) {
+        const std::vector<int> &lev = F.levels[l];
+        // extend-add, one launch per child rank (two children of one front never in the same launch: fixed summation order)
+        size_t max_kids = 0; for (int s : lev) max_kids = std::max(max_kids, kids[s].size());
+        for (size_t q = 0; q < max_kids; ++q) {
+            const size_t first = ext.size(); int gx = 1;
+            for (int s : lev) {
+                if (kids[s].size() <= q) continue;
+                const int c = kids[s][q]; const Supernode &Cn = F.sn[c];
+                if (Cn.nrows == 0) continue;
+                const int fc = Cn.ncols + Cn.nrows;
+                ExtendTask T{}; T.U = front(c) + Cn.ncols + (size_t)fc * Cn.ncols; T.P = front(s); T.rel = d_rel + Cn.rows_off; T.rc = Cn.nrows; T.fc = fc; T.fp = F.sn[s].ncols + F.sn[s].nrows;
+                ext.push_back(T); gx = std::max(gx, (Cn.nrows + 7) / 8);
+            }
+            if (ext.size() > first) launches.push_back({0, (int)first, (int)(ext.size() - first), gx});
+        }
+        int kmax = 0; for (int s : lev) kmax = std::max(kmax, F.sn[s].ncols);
+        for (int jb = 0; jb < kmax; jb += 64) {
+            const size_t pfirst = potrf.size();
+            for (int s : lev) {
+                const Supernode &S = F.sn[s]; const int k = S.ncols, f = k + S.nrows;
+                if (k <= jb) continue;
+                PotrfTask T{}; T.w = std::min(64, k - jb); T.ld = f; T.ldo = f; T.id = s;
+                T.blk = front(s) + jb + (size_t)f * jb; T.out = Pn + S.panel_off + jb + (size_t)f * jb;
+                potrf.push_back(T);
+            }
+            launches.push_back({1, (int)pfirst, (int)(potrf.size() - pfirst), 1});
+            size_t gfirst = gemm.size();
+            for (int s : lev) {      // F[below, J] <- F[below, J] Dinv^T
+                const Supernode &S = F.sn[s]; const int k = S.ncols, f = k + S.nrows;
+                if (k <= jb) continue;
+                const int w = std::min(64, k - jb);
+                double *X = front(s) + (jb + w) + (size_t)f * jb;
+                add_gemm(X, f, Pn + S.panel_off + jb + (size_t)f * jb, f, X, f, f - jb - w, w, w, GEMM_TRANS_B, 1.0, 0.0);
+            }
+            close_gemm(gfirst);
+            gfirst = gemm.size();
+            for (int s : lev) {      // F[below, below] -= F[below, J] F[below, J]^T (lower tiles)
+                const Supernode &S = F.sn[s]; const int k = S.ncols, f = k + S.nrows;
+                if (k <= jb) continue;
+                const int w = std::min(64, k - jb);
+                const double *X = front(s) + (jb + w) + (size_t)f * jb;
+                add_gemm(X, f, X, f, front(s) + (jb + w) + (size_t)f * (jb + w), f, f - jb - w, f - jb - w, w, GEMM_TRANS_B | GEMM_LOWER_TILES, -1.0, 1.0);
+            }
+            close_gemm(gfirst);
+        }
+        // P[0:k, 0:k] = L11^-1 from the block inverses, by doubling: X[bottom, top] = -X[bottom, bottom] (L[bottom, top] X[top, top]);
+        // the inner product lands (transposed) in the unused upper triangle of the front
+        const int nbmax = (kmax + 63) / 64;
+        for (int half = 1; half < nbmax; half *= 2) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const size_t gfirst = gemm.size();
+                for (int s : lev) {
+                    const Supernode &S = F.sn[s]; const int k = S.ncols, f = k + S.nrows, nb = (k + 63) / 64;
+                    for (int gb = 0; gb + half < nb; gb += 2 * half) {
+                        const int g0 = 64 * gb, sz = 64 * half, h = std::min(k, 64 * (gb + 2 * half)) - (g0 + sz);
+                        double *Tt = front(s) + g0 + (size_t)f * (g0 + sz);      // (sz x h): transpose of L[bottom, top] X[top, top]
+                        double *Ps = Pn + S.panel_off;
+                        if (pass == 0) add_gemm(Ps + g0 + (size_t)f * g0, f, front(s) + (g0 + sz) + (size_t)f * g0, f, Tt, f, sz, h, sz, GEMM_TRANS_A | GEMM_TRANS_B, 1.0, 0.0);
+                        else add_gemm(Ps + (g0 + sz) + (size_t)f * (g0 + sz), f, Tt, f, Ps + (g0 + sz) + (size_t)f * g0, f, h, sz, h, GEMM_TRANS_B, -1.0, 0.0);
+                    }
+                }
+                close_gemm(gfirst);
+            }
+        }
+        {      // P[k:f, :] = L21 L11^-1
+            const size_t gfirst = gemm.size();
+            for (int s : lev) {
+                const Supernode &S = F.sn[s]; const int k = S.ncols, f = k + S.nrows;
+                add_gemm(front(s) + k, f, Pn + S.panel_off, f, Pn + S.panel_off + k, f, S.nrows, k, k, GEMM_K_FROM_COL, 1.0, 0.0);
+            }
+            close_gemm(gfirst);
+        }
+    }
+    {      // roots: (L L^T)^-1 = L^-T L^-1, full symmetric
+        const size_t gfirst = gemm.size();
+        for (int s = 0; s < ns; ++s) {
+            const Supernode &S = F.sn[s];
+            if (S.root_inv_off < 0) continue;
+            const int k = S.ncols;
+            add_gemm(Pn + S.panel_off, k, Pn + S.panel_off, k, Pn + S.root_inv_off, root_inv_ld(k), k, k, k, GEMM_TRANS_A | GEMM_K_FROM_MAX, 1.0, 0.0);
+        }
+        close_gemm(gfirst);
+    }
+    DF_CHK(hipMalloc(&d_gemm, sizeof(GemmTask) * std::max<size_t>(gemm.size(), 1)));
+    DF_CHK(hipMalloc(&d_potrf, sizeof(PotrfTask) * std::max<size_t>(potrf.size(), 1)));
+    DF_CHK(hipMalloc(&d_ext, sizeof(ExtendTask) * std::max<size_t>(ext.size(), 1)));
+    DF_CHK(hipMemcpyAsync(d_gemm, gemm.data(), sizeof(GemmTask) * gemm.size(), hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemcpyAsync(d_potrf, potrf.data(), sizeof(PotrfTask) * potrf.size(), hipMemcpyHostToDevice, st));
+    DF_CHK(hipMemcpyAsync(d_ext, ext.data(), sizeof(ExtendTask) * ext.size(), hipMemcpyHostToDevice, st));
+    const double t_setup = now_s() - t0;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, (const int64_t *)d_adst, (const int *)d_asrc, (const double *)d_aval, d_fronts);
+    constexpr int YMAX = 32768;
+    for (const Launch &Lc : launches) {
+        for (int off = 0; off < Lc.count; off += YMAX) {
+            const int cnt = std::min(YMAX, Lc.count - off);
+            if (Lc.kind == 0) hipLaunchKernelGGL(extend_add_kernel, dim3(Lc.gx, cnt), dim3(256), 0, st, (const ExtendTask *)(d_ext + Lc.first + off));
+            else if (Lc.kind == 1) hipLaunchKernelGGL(potrf_inv_kernel, dim3(cnt), dim3(256), 0, st, (const PotrfTask *)(d_potrf + Lc.first + off), d_fail);
+            else hipLaunchKernelGGL(gemm_f64_kernel, dim3(Lc.gx, cnt), dim3(256), 0, st, (const GemmTask *)(d_gemm + Lc.first + off));
+        }
+    }
+    DF_CHK(hipGetLastError());
+    int failed = 0;
+    DF_CHK(hipMemcpyAsync(&failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    DF_CHK(hipStreamSynchronize(st));
+#undef DF_CHK
+    cleanup();
+    F.panels.clear(); F.panels.shrink_to_fit();
+    ctx->info.t_numeric_s = now_s() - t0;
+    if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: numeric factorization on the device: %.3f s (%.3f s host set-up), fronts %.2f GB, %zu launches, %zu gemm / %zu potrf / %zu extend-add tasks\n",
+                                           ctx->info.t_numeric_s, t_setup, ftot * 8e-9, launches.size(), gemm.size(), potrf.size(), ext.size());
+    if (failed) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", failed - 1);
+    return ADMM_OK;
+}
+
+// the factor's panels into ctx->d_panels (allocated): computed on the device, or on the host and copied
+int panels_to_device(admm_hip_ctx *ctx) {
+    if (ctx->device_numeric) {
+        const int rc = device_factorize(ctx);
+        if (rc != ADMM_DEVFACTOR_NOFIT) return rc;
+        fprintf(stderr, "admm_hip: the fronts do not fit the device memory that is free, factoring on the host\n");
+        const int err = factorize(ctx->A, ctx->F, std::max(1, (int)ctx->info.host_threads));
+        if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
+        ctx->info.t_numeric_s = ctx->F.t_numeric;
+    }
+    HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
     return ADMM_OK;
 }
 
@@ -588,7 +810,8 @@ int upload_factor(admm_hip_ctx *ctx) {
     std::vector<int> first(ns), ncols(ns), nrows(ns);
     std::vector<int64_t> poff(ns), roff(ns), soff(ns), foff(ns);
     for (int s = 0; s < ns; ++s) { first[s] = F.sn[s].first; ncols[s] = F.sn[s].ncols; nrows[s] = F.sn[s].nrows; poff[s] = F.sn[s].panel_off; roff[s] = F.sn[s].rows_off; soff[s] = F.sn[s].slot_off; foff[s] = F.sn[s].front_off; }
-    TRY(upload(ctx, &ctx->d_panels, F.panels));
+    TRY(dalloc(ctx, &ctx->d_panels, (size_t)std::max<int64_t>(F.panels_size, 1)));
+    TRY(panels_to_device(ctx));
     TRY(upload(ctx, &ctx->d_sn_first, first)); TRY(upload(ctx, &ctx->d_sn_ncols, ncols)); TRY(upload(ctx, &ctx->d_sn_nrows, nrows));
     TRY(upload(ctx, &ctx->d_sn_panel_off, poff)); TRY(upload(ctx, &ctx->d_sn_rows_off, roff)); TRY(upload(ctx, &ctx->d_sn_slot_off, soff));
     TRY(upload(ctx, &ctx->d_rows, F.rows));
@@ -1245,6 +1468,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_FACTOR")) ctx->device_factor = std::string(g) != "host";
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
@@ -1547,7 +1771,7 @@ int admm_hip_recompute_weights(admm_hip_ctx *ctx) {
     if (ctx->device_id >= 0) {
         HIPCHK(hipSetDevice(ctx->device_id));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
+        TRY(panels_to_device(ctx));
         if (ctx->dense && ctx->d_ainv) HIPCHK(hipMemcpy(ctx->d_ainv, ctx->Ainv.data(), ctx->Ainv.size() * sizeof(double), hipMemcpyHostToDevice));
         for (Batch &b : ctx->batches) {
             if (b.kind == ADMM_KIND_GENERIC) {
@@ -1910,6 +2134,12 @@ int admm_hip_apply_A(admm_hip_ctx *ctx, const double *x, double *y) {
 // factor.hpp on the host.  NOT used by admm_hip_step or any product path.
 int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *x) {
     if (!ctx || !ctx->finalized || !b || !x) return ADMM_ERR_ARG;
+    if (ctx->F.panels.empty() && ctx->d_panels) {      // factored on the device: the host sweeps then check the DEVICE's factor
+        ctx->F.panels.resize((size_t)ctx->F.panels_size);
+        HIPCHK(hipSetDevice(ctx->device_id));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(ctx->F.panels.data(), ctx->d_panels, sizeof(double) * ctx->F.panels.size(), hipMemcpyDeviceToHost));
+    }
     panel_solve_host(ctx->F, b, x);
     return ADMM_OK;
 }

@@ -353,21 +353,38 @@ static void do_subtree(Numeric &N, int root, std::vector<int> &loc, std::vector<
 }
 } // namespace
 
+void permuted_lower(const SymCSC &A, const Factor &F, SymCSC &PA, bool with_source) {
+    const int n = A.n;
+    PA = SymCSC(); PA.n = n;
+    std::vector<int> ti, tj; std::vector<double> tv;
+    ti.reserve(A.idx.size()); tj.reserve(A.idx.size()); tv.reserve(A.idx.size());
+    for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) {
+        int a = F.iperm[A.idx[p]], b = F.iperm[j];
+        ti.push_back(std::max(a, b)); tj.push_back(std::min(a, b)); tv.push_back(with_source ? (double)p : A.val[p]);
+    }
+    build_symcsc(n, ti, tj, tv, PA);
+}
+
+void plan_panels(Factor &F) {
+    int64_t size = 0;
+    for (Supernode &S : F.sn) size += (int64_t)(S.ncols + S.nrows) * S.ncols;
+    for (Supernode &S : F.sn) {
+        S.root_inv_off = -1;
+        if (S.parent >= 0 || S.nrows != 0 || S.ncols <= ROOT_INV_MIN_COLS) continue;
+        const int64_t off = (size + 15) & ~(int64_t)15;
+        S.root_inv_off = off;
+        size = off + (int64_t)root_inv_ld(S.ncols) * S.ncols;
+    }
+    F.panels_size = size;
+}
+
 int factorize(const SymCSC &A, Factor &F, int threads) {
     const double t0 = now_s();
     const int n = A.n, ns = (int)F.sn.size();
     if (threads < 1) threads = 1;
     // permuted lower CSC
-    SymCSC PA; PA.n = n;
-    {
-        std::vector<int> ti, tj; std::vector<double> tv;
-        ti.reserve(A.idx.size()); tj.reserve(A.idx.size()); tv.reserve(A.idx.size());
-        for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) {
-            int a = F.iperm[A.idx[p]], b = F.iperm[j];
-            ti.push_back(std::max(a, b)); tj.push_back(std::min(a, b)); tv.push_back(A.val[p]);
-        }
-        build_symcsc(n, ti, tj, tv, PA);
-    }
+    SymCSC PA;
+    permuted_lower(A, F, PA, false);
     int64_t ptot = 0;
     for (int s = 0; s < ns; ++s) ptot += (int64_t)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
     F.panels.assign(ptot, 0.0);
@@ -437,6 +454,7 @@ int factorize(const SymCSC &A, Factor &F, int threads) {
             S.root_inv_off = (int64_t)off;
         }
     }
+    F.panels_size = (int64_t)F.panels.size();
     F.t_numeric = now_s() - t0;
     return N.fail;
 }

@@ -51,6 +51,7 @@ struct Factor {
     std::vector<int> cg_slot;              // the CHILDREN's contribution slots that land on that front row (child order)
     std::vector<int> cg4;                  // [front rows][4]: the same lists when no row has more than 4 entries (-1 = none), else empty
     int64_t n_slots = 0;                   // sum of nrows
+    int64_t panels_size = 0;               // doubles in `panels` (plan_panels: the P_s, then the roots' inverses), also when the numeric phase runs on the GPU and `panels` stays empty
     int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
     int max_cols = 0, max_rows = 0;
     double t_order = 0, t_symbolic = 0, t_numeric = 0;
@@ -65,6 +66,11 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 // in one supernode): half as many elimination-tree levels for a little more fill.
 // merge_root: the top region alone does (one root supernode = top separator + the two half-separators)
 int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false);
+
+// Layout of Factor::panels from the symbolic structure alone: Supernode::root_inv_off and Factor::panels_size.
+void plan_panels(Factor &F);
+// A permuted into factor order (lower CSC).  with_source: val[q] = index of the entry of A it came from (as a double) instead of its value.
+void permuted_lower(const SymCSC &A, const Factor &F, SymCSC &PA, bool with_source);
 
 // Multifrontal numeric factorization; fills F.panels.  Returns 0 or a
 // non-zero code when A is not positive definite.

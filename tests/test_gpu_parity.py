@@ -226,6 +226,43 @@ def test_solve_residual_and_vs_oracle(pkg, monkeypatch, dense_max, leaf):
     assert np.array_equal(s.solve_only(b), s.solve_only(b))
 
 
+@pytest.mark.parametrize("dims,leaf", [((6, 5, 17), "16"), ((8, 8, 40), "0"), ((12, 12, 30), "64")])
+def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
+    """The numeric multifrontal factorization on the GPU (csrc/factor_dev.hpp: MFMA fp64 products per 64-column block, block
+    inverses, doubling for L11^-1) against the host factorization of the same symbolic structure: the panels agree to rounding,
+    the solves agree, and A x = b holds with the device's factor (System.cpp:138-140 is what both replace)."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", leaf)
+    nx, ny, nz = dims
+    monkeypatch.setenv("ADMM_HIP_FACTOR", "host")
+    sh = pkg.make_bar_system(nx, ny, nz, device_id=0)
+    sh.initialize()
+    monkeypatch.delenv("ADMM_HIP_FACTOR")
+    sd = pkg.make_bar_system(nx, ny, nz, device_id=0)
+    sd.initialize()
+    n = sd.n_nodes
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        b = rng.normal(size=3 * n)
+        xd, xh = sd.solve_only(b), sh.solve_only(b)
+        assert np.abs(sd.apply_A(xd) - b).max() < 1e-11 * np.abs(b).max()
+        assert np.abs(xd - xh).max() < 1e-11 * np.abs(xh).max()
+        assert np.abs(xd - sd.debug_panel_solve_host(b)).max() < 1e-10 * np.abs(xd).max()       # host sweeps over the DEVICE's panels
+    # re-factorization after a weight change goes through the same path
+    for s in (sd, sh):
+        s.set_weights(1, np.full(s.batch_sizes[1] if hasattr(s, "batch_sizes") else len(pkg.meshgen.bar_anchor_nodes(nx, ny)), 3.0))
+        s.recompute_weights()
+    b = rng.normal(size=3 * n)
+    xd, xh = sd.solve_only(b), sh.solve_only(b)
+    assert np.abs(sd.apply_A(xd) - b).max() < 1e-11 * np.abs(b).max()
+    assert np.abs(xd - xh).max() < 1e-11 * np.abs(xh).max()
+    # a frame of the simulation: the two factors differ in the last bits, and the Neo-Hookean line search amplifies last-bit
+    # differences of its input to ~1e-6..1e-5 within a frame (the reference against itself with a 1-ulp perturbed input:
+    # DESIGN.md section 3) -- same bound as the smoke test
+    sd.step(5); sh.step(5)
+    assert np.abs(sd.m_x - sh.m_x).max() < 5e-5
+
+
 @pytest.mark.parametrize("name,kind", [("nh", "TET_NH"), ("stvk", "TET_STVK")])
 def test_bar_one_iteration_and_trajectory(pkg, name, kind):
     g = golden("traj_bar_%s.npz" % name)
