@@ -619,6 +619,7 @@ int device_factorize(admm_hip_ctx *ctx) {
     DF_CHK(hipMemcpyAsync(d_gemm, gemm.data(), sizeof(GemmTask) * gemm.size(), hipMemcpyHostToDevice, st));
     DF_CHK(hipMemcpyAsync(d_potrf, potrf.data(), sizeof(PotrfTask) * potrf.size(), hipMemcpyHostToDevice, st));
     DF_CHK(hipMemcpyAsync(d_ext, ext.data(), sizeof(ExtendTask) * ext.size(), hipMemcpyHostToDevice, st));
+    DF_CHK(hipStreamSynchronize(st));
     const double t_setup = now_s() - t0;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, (const int64_t *)d_adst, (const int *)d_asrc, (const double *)d_aval, d_fronts);
     constexpr int YMAX = 32768;
@@ -638,8 +639,21 @@ int device_factorize(admm_hip_ctx *ctx) {
     cleanup();
     F.panels.clear(); F.panels.shrink_to_fit();
     ctx->info.t_numeric_s = now_s() - t0;
-    if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: numeric factorization on the device: %.3f s (%.3f s host set-up), fronts %.2f GB, %zu launches, %zu gemm / %zu potrf / %zu extend-add tasks\n",
-                                           ctx->info.t_numeric_s, t_setup, ftot * 8e-9, launches.size(), gemm.size(), potrf.size(), ext.size());
+    if (getenv("ADMM_HIP_VERBOSE")) {
+        double flop = 0.0;      // products as issued (triangular operands are multiplied as dense blocks from their first non-zero block on)
+        for (const GemmTask &T : gemm) {
+            const int tm = (T.m + 63) / 64, tn = (T.n + 63) / 64;
+            for (int ti = 0; ti < tm; ++ti) for (int tj = 0; tj < tn; ++tj) {
+                if ((T.flags & GEMM_LOWER_TILES) && tj > ti) continue;
+                const int k0 = (T.flags & GEMM_K_FROM_COL) ? 64 * tj : ((T.flags & GEMM_K_FROM_MAX) ? 64 * std::max(ti, tj) : 0);
+                flop += 2.0 * std::min(64, T.m - 64 * ti) * std::min(64, T.n - 64 * tj) * std::max(0, T.k - k0);
+            }
+        }
+        const double t_gpu = ctx->info.t_numeric_s - t_setup;
+        fprintf(stderr, "admm_hip: numeric factorization on the device: %.3f s = %.3f s host set-up (maps, task records, uploads) + %.3f s of kernels (%.1f GFLOP in products: %.1f TFLOP/s), "
+                        "fronts %.2f GB, %zu launches, %zu gemm / %zu potrf / %zu extend-add tasks\n",
+                ctx->info.t_numeric_s, t_setup, t_gpu, flop * 1e-9, flop / t_gpu * 1e-12, ftot * 8e-9, launches.size(), gemm.size(), potrf.size(), ext.size());
+    }
     if (failed) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", failed - 1);
     return ADMM_OK;
 }

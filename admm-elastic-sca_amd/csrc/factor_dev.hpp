@@ -136,31 +136,52 @@ __global__ __launch_bounds__(256) void potrf_inv_kernel(const PotrfTask *__restr
     if (t == 0) bad = 0;
     for (int e = t; e < 64 * 64; e += 256) { const int i = e & 63, j = e >> 6; L[i][j] = (i < w && j <= i) ? T.blk[i + (size_t)T.ld * j] : 0.0; X[i][j] = 0.0; }
     __syncthreads();
+    // right-looking, one column per step; thread (row i = t & 63, column phase t >> 6): no index arithmetic in the update
+    const int ri = t & 63, cp = t >> 6;
     for (int j = 0; j < w; ++j) {
-        if (t == 0) { const double d = L[j][j]; if (!(d > 0.0)) { bad = 1; L[j][j] = 1.0; } else L[j][j] = sqrt(d); }
+        const double d = L[j][j];                       // final since the previous step's barrier
+        const bool ok = d > 0.0;
+        const double dj = ok ? sqrt(d) : 1.0;
+        const double lij = (ri > j && ri < w) ? L[ri][j] / dj : 0.0;
+        __syncthreads();                                // everybody has read column j and the pivot
+        if (cp == 0) { if (ri == j) { L[j][j] = dj; if (!ok) bad = 1; } else if (ri > j && ri < w) L[ri][j] = lij; }
         __syncthreads();
-        const double dj = L[j][j];
-        for (int i = j + 1 + t; i < w; i += 256) L[i][j] /= dj;
-        __syncthreads();
-        // trailing lower triangle: (i, c), j < c <= i < w
-        const int rem = w - j - 1;
-        for (int e = t; e < rem * rem; e += 256) {
-            const int i = j + 1 + e % rem, c = j + 1 + e / rem;
-            if (c <= i) L[i][c] -= L[i][j] * L[c][j];
-        }
+        if (ri > j && ri < w) for (int c = j + 1 + cp; c <= ri; c += 4) L[ri][c] -= lij * L[c][j];
         __syncthreads();
     }
-    // Dinv: column c by forward substitution, one thread per column
-    if (t < w) {
-        const int c = t;
+    // Dinv by doubling inside the block (rows / columns >= w: identity): the four 16 x 16 diagonal blocks by forward substitution
+    // (one thread per column, <= 120 dependent steps instead of 2016 for the whole block), then X21 = -X22 (L21 X11) for the
+    // 32 x 32 and the 64 x 64 level with all 256 threads on the products.  T: the inner product, in the (unused) upper triangle of L.
+    for (int i = w + t; i < 64; i += 256) L[i][i] = 1.0;
+    __syncthreads();
+    if (t < 64) {
+        const int b = 16 * (t >> 4), c = b + (t & 15);
         X[c][c] = 1.0 / L[c][c];
-        for (int i = c + 1; i < w; ++i) {
+        for (int i = c + 1; i < b + 16; ++i) {
             double s = 0.0;
             for (int m = c; m < i; ++m) s += L[i][m] * X[m][c];
             X[i][c] = -s / L[i][i];
         }
     }
     __syncthreads();
+#pragma unroll 1
+    for (int sz = 16; sz < 64; sz *= 2) {
+        const int pairs = 32 / sz, per = sz * sz;          // pairs of (top, bottom) blocks of size sz; entries of one off-diagonal block
+        for (int e = t; e < pairs * per; e += 256) {       // T = L21 X11, stored transposed at L[top rows][bottom cols] (strictly upper)
+            const int p = e / per, q = e - p * per, i = q % sz, j = q / sz, g0 = 2 * sz * p;
+            double s = 0.0;
+            for (int m = j; m < sz; ++m) s += L[g0 + sz + i][g0 + m] * X[g0 + m][g0 + j];
+            L[g0 + j][g0 + sz + i] = s;
+        }
+        __syncthreads();
+        for (int e = t; e < pairs * per; e += 256) {       // X21 = -X22 T
+            const int p = e / per, q = e - p * per, i = q % sz, j = q / sz, g0 = 2 * sz * p;
+            double s = 0.0;
+            for (int m = 0; m <= i; ++m) s += X[g0 + sz + i][g0 + sz + m] * L[g0 + j][g0 + sz + m];
+            X[g0 + sz + i][g0 + j] = -s;
+        }
+        __syncthreads();
+    }
     for (int e = t; e < 64 * 64; e += 256) {
         const int i = e & 63, j = e >> 6;
         if (i < w && j < w) { if (j <= i) T.blk[i + (size_t)T.ld * j] = L[i][j]; T.out[i + (size_t)T.ldo * j] = (j <= i) ? X[i][j] : 0.0; }
