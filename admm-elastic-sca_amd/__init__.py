@@ -41,7 +41,7 @@ class Info(C.Structure):
                                          "panel_bytes", "n_supernodes", "n_levels", "max_super_cols", "max_super_rows",
                                          "solve_contrib_rows")] + \
                [(n, C.c_double) for n in ("t_order_s", "t_symbolic_s", "t_numeric_s", "t_upload_s")] + \
-               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "reserved")]
+               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -639,6 +639,7 @@ int device_factorize(admm_hip_ctx *ctx) {
     cleanup();
     F.panels.clear(); F.panels.shrink_to_fit();
     ctx->info.t_numeric_s = now_s() - t0;
+    ctx->info.device_factor = 1;
     if (getenv("ADMM_HIP_VERBOSE")) {
         double flop = 0.0;      // products as issued (triangular operands are multiplied as dense blocks from their first non-zero block on)
         for (const GemmTask &T : gemm) {
@@ -668,6 +669,7 @@ int panels_to_device(admm_hip_ctx *ctx) {
         if (err) return fail(ctx, ADMM_ERR_FACTOR, "system matrix is not positive definite (supernode %d)", err - 1);
         ctx->info.t_numeric_s = ctx->F.t_numeric;
     }
+    ctx->info.device_factor = 0;
     HIPCHK(hipMemcpy(ctx->d_panels, ctx->F.panels.data(), ctx->F.panels.size() * sizeof(double), hipMemcpyHostToDevice));
     return ADMM_OK;
 }

@@ -389,7 +389,8 @@ def main():
                                    ("x%d: elements and elimination subtrees per rank, one small all-reduce (top separators) per ADMM iteration, top of the solve replicated" % world
                                     if a.shard == "subtree" else "x%d: contiguous element shards, RHS all-reduce per ADMM iteration, replicated solve" % world)),
                    "nnz_L": info["nnz_L"], "supernodes": info["n_supernodes"], "levels": info["n_levels"],
-                   "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"], "host_threads": info["host_threads"],
+                   "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"],
+                   "factor_numeric_on": "gpu (multifrontal, fp64 MFMA products)" if info.get("device_factor") else "host", "host_threads": info["host_threads"],
                    "x_checksum": float(np.abs(xs).sum())},
         "roofline": roof,
     }

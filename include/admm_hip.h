@@ -245,7 +245,7 @@ typedef struct admm_hip_info {
     double  t_order_s, t_symbolic_s, t_numeric_s, t_upload_s; /* finalize phases */
     int32_t rank, world, device_id, host_threads;
     int32_t dense_solve;      /* 1: small system, solved as x = A_s^-1 b with the explicit inverse (see admm_hip_finalize) */
-    int32_t reserved;
+    int32_t device_factor;    /* 1: the numeric factorization ran on the GPU (csrc/factor_dev.hpp), 0: on the host */
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
 
