@@ -131,6 +131,7 @@ struct admm_hip_ctx {
     // Concurrent subtree groups on ONE GPU (ADMM_HIP_GROUPS, not with subtree sharding): the elimination tree below a small top is
     // cut into `groups` sets of independent subtrees; group 0 runs on the context's stream (levels), the others on side streams
     // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
+    bool fuse_anchor_tail = true;                 // an anchor batch right behind a tet batch goes out in the tet launch (ADMM_HIP_FUSE_ANCHORS=0: own launch)
     bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
     int groups = 1;
     std::vector<int> grp_owner;               // per supernode: group, -1 = top
@@ -1178,27 +1179,37 @@ void tet_trace_next(hipStream_t st) {
 #endif
 int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
     using namespace admm_dev;
+    bool skip_next = false;
     for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
         const Batch &b = ctx->batches[bi];
         if (only_batch >= 0 && (int)bi != only_batch) continue;
+        if (skip_next) { skip_next = false; continue; }                  // (an anchor batch that went out with the tets before it)
         if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;     // user-defined forces: generic_begin / generic_finish
         const BatchDev d = batch_dev(ctx, b);
-        const dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
+        dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
         const double *x = ctx->d_xcur;
+        // an anchor batch right behind a tet batch rides along in the tet launch (project_tet_kernel's tail)
+        BatchDev tail{}; const int tail_block0 = (int)grid.x;
+        const bool is_tet = b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK || b.kind == ADMM_KIND_TET_LINEAR || b.kind == ADMM_KIND_TET_VOLUME;
+        if (is_tet && only_batch < 0 && ctx->fuse_anchor_tail && bi + 1 < ctx->batches.size() && ctx->batches[bi + 1].kind == ADMM_KIND_ANCHOR && ctx->batches[bi + 1].n_local > 0) {
+            tail = batch_dev(ctx, ctx->batches[bi + 1]);
+            grid.x += (ctx->batches[bi + 1].n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
+            skip_next = true;
+        }
         switch (b.kind) {
         case ADMM_KIND_TET_NH:
 #ifdef ADMM_TET_PROFILE
             tet_trace_next(ctx->stream);
 #endif
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, ctx->stream, d, x);
-            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, ctx->stream, d, x);
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
+            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
             break;
         case ADMM_KIND_TET_STVK:
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, ctx->stream, d, x);
-            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, ctx->stream, d, x);
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
+            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
             break;
-        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, ctx->stream, d, x); break;
+        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, ctx->stream, d, x, tail, tail_block0); break;
+        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, ctx->stream, d, x, tail, tail_block0); break;
         case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, ctx->stream, d, x); break;
         case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, ctx->stream, d, x); break;
@@ -1484,6 +1495,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_FUSE_ANCHORS")) ctx->fuse_anchor_tail = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FACTOR")) ctx->device_factor = std::string(g) != "host";
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);

@@ -123,13 +123,42 @@ __device__ __forceinline__ void tet_load(const BatchDev &b, const double *__rest
     u.m02 = ld_stream(&b.u[(size_t)6 * n + e]); u.m12 = ld_stream(&b.u[(size_t)7 * n + e]); u.m22 = ld_stream(&b.u[(size_t)8 * n + e]);
 }
 
+// ---------------------------------------------------------------------------
+// StaticAnchor / MovingAnchor, AnchorForce.cpp:46-55, 71-89
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const double *__restrict__ x, int e) {
+    const int n = b.n;
+    if (e >= n) return;
+    const int id = b.idx[e];
+    const double s = b.w2h2[e];
+    const bool act = b.active[e] != 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
+        if (b.dx_override) dx = b.dx_override[(size_t)j * n + e];
+        const double u = b.u[(size_t)j * n + e];
+        double zi;
+        if (act) zi = b.targets[3 * (size_t)e + j];
+        else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
+        const double un = u + (dx - zi);
+        b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
+        b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
+    }
+}
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
+    project_anchor_elem(b, x, blockIdx.x * LOCAL_BLOCK + threadIdx.x);
+}
+
 template <int KIND, int M>
 #if ADMM_TET_WAVES > 0
 __global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
 #else
 __global__ __launch_bounds__(LOCAL_BLOCK)
 #endif
-void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
+void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail, int tail_block0) {
+    // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
+    // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
+    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem(tail, x, ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x); return; }
     const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= n) return;
@@ -193,30 +222,6 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x) {
 #if ADMM_PROF_ON
     if (threadIdx.x == 0) atomicAdd(&admm_dev::g_tet_prof[16], 1ull);
 #endif
-}
-
-// ---------------------------------------------------------------------------
-// StaticAnchor / MovingAnchor, AnchorForce.cpp:46-55, 71-89
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
-    const int n = b.n;
-    if (e >= n) return;
-    const int id = b.idx[e];
-    const double s = b.w2h2[e];
-    const bool act = b.active[e] != 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
-        if (b.dx_override) dx = b.dx_override[(size_t)j * n + e];
-        const double u = b.u[(size_t)j * n + e];
-        double zi;
-        if (act) zi = b.targets[3 * (size_t)e + j];
-        else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
-        const double un = u + (dx - zi);
-        b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
-        b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
-    }
 }
 
 // ---------------------------------------------------------------------------
