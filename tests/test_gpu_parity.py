@@ -263,6 +263,29 @@ def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
     assert np.abs(sd.m_x - sh.m_x).max() < 5e-5
 
 
+def test_device_factorization_disconnected_mixed_scene(pkg, monkeypatch):
+    """Two components (bar + cloth: two roots of the elimination tree, fronts from 1 to a few hundred rows, triangle / hinge /
+    anchor elements next to the tets) through the device factorization and through the host one."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "32")
+    systems = []
+    for where in ("host", None):
+        if where: monkeypatch.setenv("ADMM_HIP_FACTOR", where)
+        else: monkeypatch.delenv("ADMM_HIP_FACTOR")
+        s, _ = pkg.make_mixed_system(6, 6, 14, 14, 14, device_id=0)
+        s.initialize()
+        systems.append(s)
+    sh, sd = systems
+    assert sh.info()["device_factor"] == 0 and sd.info()["device_factor"] == 1
+    n = sd.n_nodes
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        b = rng.normal(size=3 * n)
+        xd, xh = sd.solve_only(b), sh.solve_only(b)
+        assert np.abs(sd.apply_A(xd) - b).max() < 1e-11 * np.abs(b).max()
+        assert np.abs(xd - xh).max() < 1e-11 * np.abs(xh).max()
+
+
 @pytest.mark.parametrize("name,kind", [("nh", "TET_NH"), ("stvk", "TET_STVK")])
 def test_bar_one_iteration_and_trajectory(pkg, name, kind):
     g = golden("traj_bar_%s.npz" % name)
