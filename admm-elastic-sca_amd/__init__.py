@@ -120,6 +120,8 @@ def lib():
         L.admm_hip_apply_A.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_panel_solve_host.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, _dp, _dp]
+        L.admm_hip_debug_gemm.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_double, C.c_double, _dp, C.c_int64, _dp, C.c_int64, _dp, C.c_int64]
+        L.admm_hip_debug_potrf_inv.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
         L.admm_hip_add_generic_batch.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int64, _ip, _ip, _dp, _dp, C.POINTER(C.c_int)]
         L.admm_hip_set_project_hook.argtypes = [C.c_void_p, PROJECT_FN, C.c_void_p]
         L.admm_hip_rccl_unique_id.argtypes = [C.c_void_p]
@@ -432,6 +434,22 @@ class System:
         y = np.empty_like(x)
         self._chk(self.L.admm_hip_debug_math(self.h, int(op), x.size, _d(x), _d(y)))
         return y
+
+    def debug_gemm(self, A, B, Cm, m, n, k, flags=0, alpha=1.0, beta=0.0):
+        """gemm_f64_kernel on column-major (Fortran-ordered) 2-D arrays; Cm is updated in place and returned."""
+        A = np.asfortranarray(A, dtype=np.float64); B = np.asfortranarray(B, dtype=np.float64)
+        assert Cm.flags.f_contiguous and Cm.dtype == np.float64
+        self._chk(self.L.admm_hip_debug_gemm(self.h, m, n, k, A.shape[0], B.shape[0], Cm.shape[0], flags, alpha, beta,
+                                             _d(A), A.size, _d(B), B.size, _d(Cm), Cm.size))
+        return Cm
+
+    def debug_potrf_inv(self, blk):
+        """potrf_inv_kernel: (L, L^-1) of a symmetric positive definite block of at most 64 rows."""
+        w = blk.shape[0]
+        Lm = np.asfortranarray(blk, dtype=np.float64).copy(order="F")
+        X = np.zeros_like(Lm, order="F")
+        self._chk(self.L.admm_hip_debug_potrf_inv(self.h, w, w, _d(Lm), _d(X)))
+        return np.tril(Lm), X
 
     def debug_panel_solve_host(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64).ravel()

@@ -2178,6 +2178,37 @@ __global__ void debug_math_kernel(int op, int64_t n, const double *__restrict__ 
     if (i < n) out[i] = op == 0 ? admm_log(in[i]) : admm_exp(in[i]);
 }
 } // namespace admm_dev
+int admm_hip_debug_gemm(admm_hip_ctx *ctx, int m, int n, int k, int lda, int ldb, int ldc, int flags, double alpha, double beta,
+                        const double *A, int64_t size_a, const double *B, int64_t size_b, double *C, int64_t size_c) {
+    TRY(require_device(ctx));
+    if (!A || !B || !C || m < 1 || n < 1 || k < 1 || size_a < 1 || size_b < 1 || size_c < 1) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr; admm_dev::GemmTask *dT = nullptr;
+    auto done = [&](int rc) { for (void *p : {(void *)dA, (void *)dB, (void *)dC, (void *)dT}) if (p) (void)hipFree(p); return rc ? fail(ctx, rc, "debug_gemm failed") : ADMM_OK; };
+    if (hipMalloc(&dA, 8 * size_a) != hipSuccess || hipMalloc(&dB, 8 * size_b) != hipSuccess || hipMalloc(&dC, 8 * size_c) != hipSuccess || hipMalloc(&dT, sizeof(admm_dev::GemmTask)) != hipSuccess) return done(ADMM_ERR_HIP);
+    if (hipMemcpy(dA, A, 8 * size_a, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dB, B, 8 * size_b, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dC, C, 8 * size_c, hipMemcpyHostToDevice) != hipSuccess) return done(ADMM_ERR_HIP);
+    admm_dev::GemmTask T{}; T.A = dA; T.B = dB; T.C = dC; T.m = m; T.n = n; T.k = k; T.lda = lda; T.ldb = ldb; T.ldc = ldc; T.flags = flags; T.alpha = alpha; T.beta = beta;
+    if (hipMemcpy(dT, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return done(ADMM_ERR_HIP);
+    hipLaunchKernelGGL(admm_dev::gemm_f64_kernel, dim3(((m + 63) / 64) * ((n + 63) / 64), 1), dim3(256), 0, ctx->stream, (const admm_dev::GemmTask *)dT);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(C, dC, 8 * size_c, hipMemcpyDeviceToHost) != hipSuccess) return done(ADMM_ERR_HIP);
+    return done(ADMM_OK);
+}
+int admm_hip_debug_potrf_inv(admm_hip_ctx *ctx, int w, int ld, double *blk, double *out) {
+    TRY(require_device(ctx));
+    if (!blk || !out || w < 1 || w > 64 || ld < w) return ADMM_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    const size_t sz = 8 * (size_t)ld * w;
+    double *dB = nullptr, *dO = nullptr; admm_dev::PotrfTask *dT = nullptr; int *dF = nullptr;
+    auto done = [&](int rc) { for (void *p : {(void *)dB, (void *)dO, (void *)dT, (void *)dF}) if (p) (void)hipFree(p); return rc; };
+    if (hipMalloc(&dB, sz) != hipSuccess || hipMalloc(&dO, sz) != hipSuccess || hipMalloc(&dT, sizeof(admm_dev::PotrfTask)) != hipSuccess || hipMalloc(&dF, sizeof(int)) != hipSuccess) return done(fail(ctx, ADMM_ERR_HIP, "debug_potrf_inv: hipMalloc"));
+    admm_dev::PotrfTask T{}; T.blk = dB; T.out = dO; T.w = w; T.ld = ld; T.ldo = ld; T.id = 0;
+    if (hipMemcpy(dB, blk, sz, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dO, 0, sz) != hipSuccess || hipMemset(dF, 0, sizeof(int)) != hipSuccess || hipMemcpy(dT, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return done(fail(ctx, ADMM_ERR_HIP, "debug_potrf_inv: copy"));
+    hipLaunchKernelGGL(admm_dev::potrf_inv_kernel, dim3(1), dim3(256), 0, ctx->stream, (const admm_dev::PotrfTask *)dT, dF);
+    int failed = 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(blk, dB, sz, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out, dO, sz, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&failed, dF, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(ctx, ADMM_ERR_HIP, "debug_potrf_inv: run"));
+    return done(failed ? fail(ctx, ADMM_ERR_FACTOR, "block is not positive definite") : ADMM_OK);
+}
 int admm_hip_debug_math(admm_hip_ctx *ctx, int op, int64_t n, const double *in, double *out) {
     TRY(require_device(ctx));
     if (!in || !out || n < 0 || op < 0 || op > 1) return ADMM_ERR_ARG;

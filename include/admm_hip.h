@@ -234,6 +234,15 @@ int admm_hip_debug_panel_solve_host(admm_hip_ctx *ctx, const double *b, double *
 /* the device's log() / exp() (glibc's algorithms restated, local_math.hpp admm_log / admm_exp) applied to n doubles:
  * op 0 = log, 1 = exp.  Parity tests compare them bit for bit with the host's libm.                                */
 int admm_hip_debug_math(admm_hip_ctx *ctx, int op, int64_t n, const double *in, double *out);
+/* Unit-test hooks for the kernels of the device factorization (csrc/factor_dev.hpp), host arrays in and out, column-major:
+ *  gemm:      C (m x n, ldc) = beta C + alpha opA(A) opB(B) through gemm_f64_kernel; flags: 1 A transposed (stored k x m), 2 B transposed
+ *             (stored n x k), 4 only tiles on / below the diagonal, 8 sum from the tile's first column, 16 from max(tile row, tile column);
+ *             size_a / size_b / size_c: doubles in the arrays.
+ *  potrf_inv: blk (w x w, ld, w <= 64; lower triangle read) <- its Cholesky factor, out (w x w, ld) <- the factor's inverse;
+ *             returns ADMM_ERR_FACTOR when a pivot is not positive.                                                              */
+int admm_hip_debug_gemm(admm_hip_ctx *ctx, int m, int n, int k, int lda, int ldb, int ldc, int flags, double alpha, double beta,
+                        const double *A, int64_t size_a, const double *B, int64_t size_b, double *C, int64_t size_c);
+int admm_hip_debug_potrf_inv(admm_hip_ctx *ctx, int w, int ld, double *blk, double *out);
 
 typedef struct admm_hip_info {
     int64_t n_nodes, n_elems_total, n_elems_local, rows_compact;

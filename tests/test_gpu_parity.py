@@ -263,6 +263,68 @@ def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
     assert np.abs(sd.m_x - sh.m_x).max() < 5e-5
 
 
+@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (1, 1, 1), (130, 70, 37), (200, 200, 64), (65, 129, 200), (333, 5, 17)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_gemm_f64_kernel(pkg, m, n, k, flags):
+    """The fp64 MFMA product kernel of the device factorization (csrc/factor_dev.hpp gemm_f64_kernel) against numpy: every
+    operand orientation, ragged sizes, alpha / beta, leading dimensions larger than the extents."""
+    s = pkg.make_bar_system(2, 2, 3); s.initialize()
+    rng = np.random.default_rng(m * 1000 + n * 10 + k + flags)
+    ta, tb = flags & 1, flags & 2
+    A = np.asfortranarray(rng.normal(size=((k if ta else m) + 3, (m if ta else k))))      # leading dimension = extent + 3
+    B = np.asfortranarray(rng.normal(size=((n if tb else k) + 2, (k if tb else n))))
+    Cm = np.asfortranarray(rng.normal(size=(m + 5, n)))
+    opA = A[:k, :m].T if ta else A[:m, :k]
+    opB = B[:n, :k].T if tb else B[:k, :n]
+    want = Cm.copy(order="F")
+    want[:m, :n] = 0.75 * want[:m, :n] - 1.5 * (opA @ opB)
+    got = s.debug_gemm(A, B, Cm, m, n, k, flags=flags, alpha=-1.5, beta=0.75)
+    assert np.array_equal(got[m:], want[m:])                       # rows beyond m untouched
+    assert np.abs(got[:m] - want[:m]).max() <= 1e-13 * k * max(1.0, np.abs(want).max())
+
+
+def test_gemm_f64_kernel_triangular_flags(pkg):
+    """The structure flags: lower tiles only (symmetric update), K from the tile's column (lower triangular B), K from
+    max(row, column) tile (A^T A of a lower triangular A)."""
+    s = pkg.make_bar_system(2, 2, 3); s.initialize()
+    rng = np.random.default_rng(11)
+    n = 150
+    Lo = np.asfortranarray(np.tril(rng.normal(size=(n, n))))
+    A = np.asfortranarray(rng.normal(size=(n, 64)))
+    C0 = np.asfortranarray(rng.normal(size=(n, n)))
+    got = s.debug_gemm(A, A, C0.copy(order="F"), n, n, 64, flags=2 | 4, alpha=-1.0, beta=1.0)        # C -= A A^T, tiles on / below the diagonal
+    want = C0 - A @ A.T
+    for ti in range(3):
+        for tj in range(3):
+            blk = (slice(64 * ti, min(n, 64 * ti + 64)), slice(64 * tj, min(n, 64 * tj + 64)))
+            if tj <= ti: assert np.abs(got[blk] - want[blk]).max() < 1e-12
+            else: assert np.array_equal(got[blk], C0[blk])
+    R = np.asfortranarray(rng.normal(size=(90, n)))
+    got = s.debug_gemm(R, Lo, np.zeros((90, n), order="F"), 90, n, n, flags=8)                      # R Lo, Lo lower triangular
+    assert np.abs(got - R @ Lo).max() < 1e-12 * n
+    got = s.debug_gemm(Lo, Lo, np.zeros((n, n), order="F"), n, n, n, flags=1 | 16)                     # Lo^T Lo
+    assert np.abs(got - Lo.T @ Lo).max() < 1e-12 * n
+
+
+@pytest.mark.parametrize("w", [1, 2, 15, 16, 17, 33, 63, 64])
+def test_potrf_inv_kernel(pkg, w):
+    """Cholesky of a diagonal block and the factor's inverse (potrf_inv_kernel) against numpy; a block that is not positive
+    definite is reported."""
+    s = pkg.make_bar_system(2, 2, 3); s.initialize()
+    rng = np.random.default_rng(w)
+    M = rng.normal(size=(w, w + 3))
+    S = M @ M.T + 0.1 * np.eye(w)
+    Lg, Xg = s.debug_potrf_inv(S)
+    Lw = np.linalg.cholesky(S)
+    assert np.abs(Lg - Lw).max() < 1e-12 * np.abs(Lw).max()
+    assert np.abs(Xg @ Lw - np.eye(w)).max() < 1e-10
+    assert np.array_equal(np.triu(Xg, 1), np.zeros((w, w)))
+    if w > 1:
+        S[w - 1, w - 1] = -1.0
+        with pytest.raises(Exception):
+            s.debug_potrf_inv(S)
+
+
 def test_device_factorization_disconnected_mixed_scene(pkg, monkeypatch):
     """Two components (bar + cloth: two roots of the elimination tree, fronts from 1 to a few hundred rows, triangle / hinge /
     anchor elements next to the tets) through the device factorization and through the host one."""
