@@ -46,6 +46,7 @@ struct Batch {
     int max_iter = 0;                            // largest L-BFGS max_iterations (hyperelastic kinds)
     // device
     int *d_idx = nullptr, *d_dst = nullptr, *d_active = nullptr, *d_niters = nullptr;
+    int *d_order = nullptr; unsigned int *d_cost = nullptr; int n_blocks_ordered = 0;      // tets: launch order by last frame's cost (see project_tet_kernel)
     double *d_rest = nullptr, *d_par = nullptr, *d_w2h2 = nullptr, *d_kblend = nullptr, *d_w2 = nullptr;
     double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
@@ -131,6 +132,8 @@ struct admm_hip_ctx {
     // Concurrent subtree groups on ONE GPU (ADMM_HIP_GROUPS, not with subtree sharding): the elimination tree below a small top is
     // cut into `groups` sets of independent subtrees; group 0 runs on the context's stream (levels), the others on side streams
     // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
+    bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
+    int64_t frames = 0;
     bool fuse_anchor_tail = true;                 // an anchor batch right behind a tet batch goes out in the tet launch (ADMM_HIP_FUSE_ANCHORS=0: own launch)
     bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
     int groups = 1;
@@ -1094,6 +1097,18 @@ int upload_all(admm_hip_ctx *ctx) {
         TRY(upload(ctx, &b.d_state, st));
         TRY(dalloc(ctx, &b.d_niters, (size_t)std::max(nl, 1)));
         HIPCHK(hipMemset(b.d_niters, 0, sizeof(int) * (size_t)std::max(nl, 1)));
+        b.d_order = nullptr; b.d_cost = nullptr; b.n_blocks_ordered = 0;
+        {
+            // more blocks than the chip holds at once (2 waves x 4 SIMDs x 256 CUs): the launch order matters
+            const int nblk = (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK;
+            if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && ctx->tet_order && nblk > ctx->tet_order_min_blocks) {
+                std::vector<int> ident(nblk); std::iota(ident.begin(), ident.end(), 0);
+                TRY(upload(ctx, &b.d_order, ident));
+                TRY(dalloc(ctx, &b.d_cost, (size_t)nblk));
+                HIPCHK(hipMemset(b.d_cost, 0, sizeof(unsigned int) * (size_t)nblk));
+                b.n_blocks_ordered = nblk;
+            }
+        }
         if (b.kind == ADMM_KIND_ANCHOR) {
             std::vector<double> tg((size_t)3 * std::max(nl, 1), 0.0); std::vector<int> ac(std::max(nl, 1), 1);
             for (int el = 0; el < nl; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)b.local[el] + j]; ac[el] = b.active[b.local[el]]; }
@@ -1154,6 +1169,7 @@ BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
     d.fslot = ctx->d_fslot; d.dst = b.d_dst; d.targets = b.d_targets; d.active = b.d_active;
     d.dx_override = b.d_dx_override;
+    d.order = b.d_order; d.cost = b.d_cost;
     return d;
 }
 
@@ -1489,12 +1505,16 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     const char *ls = getenv("ADMM_HIP_LEAF");
     if (ls && atoi(ls) > 0) ctx->leaf_size = atoi(ls);
     if (const char *g = getenv("ADMM_HIP_GRAPH")) { ctx->graph_enabled = atoi(g) != 0; ctx->graph_forced = ctx->graph_enabled; }
+#if defined(ADMM_TET_PROFILE) || defined(ADMM_TET_TIMELINE) || defined(ADMM_SWEEP_PROFILE)
+    ctx->graph_enabled = false;      // diagnostic builds: eager launches only (their per-launch symbol updates are not capturable)
+#endif
     if (const char *g = getenv("ADMM_HIP_GRAPH_COMM")) ctx->graph_comm = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_TET_ORDER")) ctx->tet_order = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FUSE_ANCHORS")) ctx->fuse_anchor_tail = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FACTOR")) ctx->device_factor = std::string(g) != "host";
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
@@ -1686,6 +1706,20 @@ int admm_hip_debug_node_owner(admm_hip_ctx *ctx, int32_t *owner) {
     for (int i = 0; i < ctx->n_nodes; ++i) owner[i] = (ctx->shard_mode == ADMM_SHARD_SUBTREE && ctx->world > 1) ? ctx->node_owner[ctx->F.iperm[i]] : 0;
     return ADMM_OK;
 }
+#ifdef ADMM_TET_TIMELINE
+// wave timeline of the NEXT tet launches (the buffer is overwritten by every launch: read it after the one of interest)
+static unsigned long long *g_wave_t_buf; static size_t g_wave_t_n;
+extern "C" int admm_hip_debug_tet_wave_times(long n_waves, unsigned long long *out) {
+    if (!out) {      // arm
+        hipFree(g_wave_t_buf); g_wave_t_buf = nullptr; g_wave_t_n = (size_t)n_waves;
+        if (n_waves > 0 && hipMalloc(&g_wave_t_buf, 16 * g_wave_t_n) != hipSuccess) return ADMM_ERR_HIP;
+        if (n_waves > 0) hipMemset(g_wave_t_buf, 0, 16 * g_wave_t_n);
+        return hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_tet_wave_t), &g_wave_t_buf, sizeof(g_wave_t_buf)) == hipSuccess ? ADMM_OK : ADMM_ERR_HIP;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, g_wave_t_buf, 16 * g_wave_t_n, hipMemcpyDeviceToHost) != hipSuccess) return ADMM_ERR_HIP;
+    return ADMM_OK;
+}
+#endif
 #ifdef ADMM_SWEEP_PROFILE
 // -> stamps[4 * workgroups], meta[6 * launches]; returns the number of launches (negative: error; call with NULL for the sizes)
 extern "C" long admm_hip_debug_sweep_profile_read(unsigned long long *stamps, int *meta) {
@@ -1854,6 +1888,8 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     // event layout (timing mode): E0 | prologue | E1 | per TIMED iteration: S local E rhs E allreduce E [exchange: E E] fwd E bwd E | Ea | epilogue | Eb
     ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_timed = 0; ctx->ev_pending = ctx->timing;
     TRY(mark(ctx));
+    if (ctx->frames++ > 0)      // the blocks of the large tet batches by what they cost in the frame before
+        for (const Batch &b : ctx->batches) if (b.n_blocks_ordered) hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.n_blocks_ordered, b.d_cost, b.d_order);
     if (ctx->explicit_simple) {
         hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
     } else {

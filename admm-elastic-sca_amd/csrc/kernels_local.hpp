@@ -60,6 +60,8 @@ struct BatchDev {
     double *targets;       // anchors: [n][3]
     const int *active;     // anchors: [n]
     const double *dx_override; // parity tests: SoA [rows][n] of D_i x to use instead of the gather (NULL in production)
+    const int *order;      // tets, large batches: which 64-tet block workgroup i processes (costliest blocks of the last frame first), or NULL
+    unsigned int *cost;    // [blocks]: real-time ticks every block took, summed over a frame (feeds `order`), or NULL
 };
 
 ADMM_HD Mat3 mat_add(const Mat3 &a, const Mat3 &b) {
@@ -123,6 +125,31 @@ __device__ __forceinline__ void tet_load(const BatchDev &b, const double *__rest
     u.m02 = ld_stream(&b.u[(size_t)6 * n + e]); u.m12 = ld_stream(&b.u[(size_t)7 * n + e]); u.m22 = ld_stream(&b.u[(size_t)8 * n + e]);
 }
 
+// order[] <- the blocks by descending cost (256 buckets of cost / max; the order inside a bucket is whatever the atomics give: it
+// only decides when a block starts, never what it computes); cost[] <- 0.  One workgroup.
+__global__ __launch_bounds__(1024) void order_by_cost_kernel(int n_blocks, unsigned int *__restrict__ cost, int *__restrict__ order) {
+    __shared__ unsigned int hist[256], start[256], mx;
+    const int t = threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    if (t == 0) mx = 1;
+    __syncthreads();
+    unsigned int m = 0;
+    for (int i = t; i < n_blocks; i += 1024) m = max(m, cost[i]);
+    atomicMax(&mx, m);
+    __syncthreads();
+    const unsigned long long top = mx;
+    for (int i = t; i < n_blocks; i += 1024) atomicAdd(&hist[255 - (unsigned int)((unsigned long long)cost[i] * 255ull / top)], 1u);
+    __syncthreads();
+    if (t == 0) { unsigned int acc = 0; for (int q = 0; q < 256; ++q) { start[q] = acc; acc += hist[q]; } }
+    __syncthreads();
+    for (int i = t; i < n_blocks; i += 1024) {
+        const unsigned int q = 255 - (unsigned int)((unsigned long long)cost[i] * 255ull / top);
+        order[atomicAdd(&start[q], 1u)] = i;
+    }
+    __syncthreads();
+    for (int i = t; i < n_blocks; i += 1024) cost[i] = 0;
+}
+
 // ---------------------------------------------------------------------------
 // StaticAnchor / MovingAnchor, AnchorForce.cpp:46-55, 71-89
 // ---------------------------------------------------------------------------
@@ -159,12 +186,18 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
     // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
     // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
     if ((int)blockIdx.x >= tail_block0) { project_anchor_elem(tail, x, ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x); return; }
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    // Launch order by cost: a block's time depends on its slowest line search (2-4 or 20 evaluations, spatially clustered); in mesh
+    // order the expensive blocks of the 1M-tet bar come last and the launch ends with a 50 us tail of a few hundred waves.  The blocks
+    // that took longest in the last frame start first (order_by_cost_kernel, once per frame); results do not depend on the order.
+    const int blk = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+    const unsigned long long t_begin = b.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int e = blk * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= n) return;
     double B[12];
     Mat3 Dx, u, F, z;
     ADMM_PROF_T0
+    ADMM_TET_STAMP(e, 0);
     tet_load(b, x, e, n, B, Dx, u);
     F = mat_add(Dx, u);
     ADMM_PROF_TIME(0);
@@ -222,6 +255,8 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
 #if ADMM_PROF_ON
     if (threadIdx.x == 0) atomicAdd(&admm_dev::g_tet_prof[16], 1ull);
 #endif
+    ADMM_TET_STAMP(e, 1);
+    if (b.cost && threadIdx.x == 0) b.cost[blk] += (unsigned int)(__builtin_amdgcn_s_memrealtime() - t_begin);
 }
 
 // ---------------------------------------------------------------------------

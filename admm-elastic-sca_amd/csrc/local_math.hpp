@@ -30,6 +30,15 @@
 
 namespace admm_dev {
 
+// ---- wave timeline of the tet kernel (tools/probe/tet_timeline.py; build flag -DADMM_TET_TIMELINE, never on in the shipped library):
+// the first lane of every wave stamps the 100 MHz real-time counter at its start and at its end -- nothing else is added
+#if defined(ADMM_TET_TIMELINE) && defined(__HIPCC__)
+__device__ unsigned long long *g_tet_wave_t;
+#define ADMM_TET_STAMP(e, slot) do { if (admm_dev::g_tet_wave_t && (threadIdx.x & 63) == 0) admm_dev::g_tet_wave_t[2 * (size_t)((e) >> 6) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ADMM_TET_STAMP(e, slot)
+#endif
+
 // ---- phase attribution of the tet kernel (tools/tet_phase_profile.py; build flag -DADMM_TET_PROFILE, never on in the
 // shipped library): s_memtime deltas accumulated by lane 0 of every wave, per-lane loop counts as (sum, 64 x wave maximum)
 #if defined(ADMM_TET_PROFILE) && defined(__HIPCC__)
