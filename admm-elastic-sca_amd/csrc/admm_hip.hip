@@ -155,6 +155,10 @@ struct admm_hip_ctx {
     // eagerly (0.780 vs 0.766-0.775 ms per iteration, tools/graph_vs_eager.py).  ADMM_HIP_GRAPH=1 forces it, 0 disables it.
     bool graph_enabled = true, graph_forced = false; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
+    // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
+    // instead of a second round of workgroups for the few that did not fit (1M-tet bar: levels 3, 4, 6, 7 with 8.6-13.7 k columns:
+    // backward 0.212 -> 0.203 ms; including the top levels with 4.5-5.5 k columns: 0.229).  ADMM_HIP_BWD_CW2_MIN / _MAX, MIN 0 = off
+    int bwd_cw2_min_cols = 8192, bwd_cw2_max_cols = 16384;
     int bwd_nw = 8, bwd_small_nw = 4;                               // backward sweep, levels of wide supernodes: waves (= columns) per block sharing one staging (ADMM_HIP_BWD_NW = 4 / 8 / 16)
     int xcd_min_supernodes = 16;                  // levels with at least this many supernodes get the XCD-aware item order (0 = off; ADMM_HIP_XCD)
     int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
@@ -883,6 +887,7 @@ int upload_factor(admm_hip_ctx *ctx) {
             int level_cols = 0;
             for (int s : F.levels[l]) if (!own || (*own)[s] == ps.want) level_cols += F.sn[s].ncols;
             L.bwd_nw = bwd_small ? ctx->bwd_small_nw : (level_cols >= ctx->bwd_nw_min_cols ? ctx->bwd_nw : 4);
+            if (!bwd_small && ctx->bwd_cw2_min_cols > 0 && level_cols > ctx->bwd_cw2_min_cols && level_cols <= ctx->bwd_cw2_max_cols) L.bwd_cw = 2;
             for (int s : F.levels[l]) {
                 if (own && (*own)[s] != ps.want) continue;
                 const Supernode &S = F.sn[s];
@@ -1312,6 +1317,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
             if (L.bwd_cw == 4 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<4, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_cw == 4 && L.bwd_nw == 2) hipLaunchKernelGGL((solve_bwd_kernel<4, 2>), dim3(L.n_bwd), dim3(128), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            else if (L.bwd_cw == 2 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<2, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<1, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
             else if (L.bwd_nw == 16) hipLaunchKernelGGL((solve_bwd_kernel<1, 16>), dim3(L.n_bwd), dim3(1024), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
@@ -1517,6 +1523,8 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_TET_ORDER")) ctx->tet_order = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FUSE_ANCHORS")) ctx->fuse_anchor_tail = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FACTOR")) ctx->device_factor = std::string(g) != "host";
+    if (const char *g = getenv("ADMM_HIP_BWD_CW2_MIN")) ctx->bwd_cw2_min_cols = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_BWD_CW2_MAX")) ctx->bwd_cw2_max_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
