@@ -322,6 +322,9 @@ __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const 
 #ifndef ADMM_FWD_SMALL_WAVES
 #define ADMM_FWD_SMALL_WAVES 4    // wave items per block in the narrow-supernode forward kernel
 #endif
+#ifndef ADMM_BWD_UNROLL2
+#define ADMM_BWD_UNROLL2 1        // 64-row groups per load batch in the CW = 2 backward kernel (1 / 2 / 4: 0.198-0.199 / 0.198-0.201 / 0.202-0.203 ms backward at 1M tets)
+#endif
 #ifndef ADMM_BWD_PREFETCH
 #define ADMM_BWD_PREFETCH 1       // CW > 1 backward kernel: first panel rows requested before the staging barrier
 #endif
@@ -564,19 +567,32 @@ __global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__
                     if (i >= j0) { const double p = Pj[i]; const double *v = &vs[3 * q]; acc[0][0] += p * v[0]; acc[0][1] += p * v[1]; acc[0][2] += p * v[2]; }
                 }
             } else {
-                for (int q = lane; q < rc; q += 64) {
+                int q = lane;
+                if (ADMM_BWD_PREFETCH && r0 == jc0 && q < rc) {      // the rows requested before the staging barrier
+                    const double *v = &vs[3 * q];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) { acc[c][0] += pf[c] * v[0]; acc[c][1] += pf[c] * v[1]; acc[c][2] += pf[c] * v[2]; }
+                    q += 64;
+                }
+                constexpr int UC = CW == 2 ? ADMM_BWD_UNROLL2 : 1;
+                for (; q + 64 * (UC - 1) < rc; q += 64 * UC) {
+                    double p[UC][CW];
+#pragma unroll
+                    for (int u = 0; u < UC; ++u)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) { const int i = r0 + q + 64 * u; p[u][c] = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < UC; ++u) {
+                        const double *v = &vs[3 * (q + 64 * u)];
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) { acc[c][0] += p[u][c] * v[0]; acc[c][1] += p[u][c] * v[1]; acc[c][2] += p[u][c] * v[2]; }
+                    }
+                }
+                for (; q < rc; q += 64) {
                     const int i = r0 + q;
                     const double *v = &vs[3 * q];
-                    double p[CW];
-                    if (ADMM_BWD_PREFETCH && r0 == jc0 && q == lane) {
 #pragma unroll
-                        for (int c = 0; c < CW; ++c) p[c] = pf[c];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < CW; ++c) p[c] = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0;
-                    }
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) { acc[c][0] += p[c] * v[0]; acc[c][1] += p[c] * v[1]; acc[c][2] += p[c] * v[2]; }
+                    for (int c = 0; c < CW; ++c) { const double p = (j0 + c < k && i >= j0 + c) ? Pj[i + (size_t)f * c] : 0.0; acc[c][0] += p * v[0]; acc[c][1] += p * v[1]; acc[c][2] += p * v[2]; }
                 }
             }
         }
