@@ -134,6 +134,7 @@ struct admm_hip_ctx {
     // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;
+    int merge_small = 0;                          // dissection regions of at most that many nodes become four-way tree nodes (ADMM_HIP_MERGE_SMALL)
     bool fuse_anchor_tail = true;                 // an anchor batch right behind a tet batch goes out in the tet launch (ADMM_HIP_FUSE_ANCHORS=0: own launch)
     bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
     int groups = 1;
@@ -405,7 +406,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // HBM-rate product of k^2 doubles (3335^2 x 8 B = 89 MB at the 1M-tet bar)
         bool merge_root = merge_above == 0 && ctx->root_inverse;
         if (const char *e = getenv("ADMM_HIP_MERGE_ROOT")) merge_root = atoi(e) != 0;
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root);
+        int merge_small = ctx->merge_small;
+        if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small);
     }
     // numeric phase: on the device when there is one (device_factorize, from upload_factor / recompute_weights); the small-system
     // inverse and device-less contexts (CPU tests of the host factorization) factor here

@@ -119,10 +119,11 @@ struct ND {
     // top levels of both sweeps, where every launch is latency, collapse into one product.
     int merge = 0;
     bool merge_root = false;
+    int merge_small = 0;      // regions of at most that many nodes (and more than a leaf) become four-way nodes as well: one level less near the leaves
     int rec(std::vector<int> &nodes, int depth = 0) {
         const int m = (int)nodes.size();
         if (m <= leaf) return emit(nodes);
-        bool four = (merge > 0 && m > merge) || (merge_root && depth == 0);
+        bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small);
         std::vector<int> L, R, sep;
         bisect(nodes, L, R, sep);
         // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
@@ -151,7 +152,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -165,7 +166,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root;
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
