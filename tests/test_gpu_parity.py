@@ -325,6 +325,22 @@ def test_potrf_inv_kernel(pkg, w):
             s.debug_potrf_inv(S)
 
 
+def test_frames_bitwise_reproducible(pkg):
+    """Two fresh systems of one scene give bitwise equal states after several frames: the device factorization has a fixed summation
+    order, the sweeps have no atomics, and the cost-ordered launch of the tet blocks (active here: 3 264 blocks) only decides when a
+    block runs, never what it computes."""
+    states = []
+    for _ in range(2):
+        s = pkg.make_bar_system(32, 32, 34)
+        s.initialize()
+        assert s.info()["device_factor"] == 1
+        for _ in range(3):
+            s.step(10)
+        states.append((s.m_x.copy(), s.m_v.copy()))
+        del s
+    assert np.array_equal(states[0][0], states[1][0]) and np.array_equal(states[0][1], states[1][1])
+
+
 def test_device_factorization_disconnected_mixed_scene(pkg, monkeypatch):
     """Two components (bar + cloth: two roots of the elimination tree, fronts from 1 to a few hundred rows, triangle / hinge /
     anchor elements next to the tets) through the device factorization and through the host one."""
