@@ -414,22 +414,39 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
     const int jend = (full || i >= k) ? k : i + 1;
     // columns beyond the tile's last row never contribute to a tile inside the triangle
     const int kneed = full ? k : min(k, (tile * 64 + 64 <= k) ? tile * 64 + 64 : k);
-    // the carry of the tile's rows does not depend on this supernode: request it first
+    // The path to the staging barrier in dependency order (vector loads complete in issue order): (1) the index quadruples of this
+    // thread's carry row and of its first staged column + that column's right-hand side; (2) the contribution values they point to,
+    // first and second slot together (an absent one reads slot 0 and counts as zero); the staged vector goes to LDS; (3) only then
+    // the first group of panel columns (cold: the burst of all workgroups takes ~3 us to land) and a barrier that waits for LDS
+    // alone, so the burst overlaps the barrier and the first LDS reads.  Before: carry chain, panel request + a barrier waiting
+    // for it, staging chain, barrier -- three latencies in a row (probe stamps).
+    const int kc_first = min(FWD_BIG_KCHUNK, kneed);
+    const bool pre_ts = CG2 && (int)threadIdx.x < kc_first;          // this thread's first staged column
+    const int c_ln = threadIdx.x / 3, c_c = threadIdx.x - 3 * c_ln, c_row = tile * 64 + c_ln;
+    const bool pre_carry = threadIdx.x < 192 && c_row < f && c_row >= k;
     double carry = 0.0;
-    if (threadIdx.x < 192) {
-        const int ln = threadIdx.x / 3, c = threadIdx.x - 3 * ln;
-        const int row = tile * 64 + ln;
-        if (row < f && row >= k) {
-            if (CG2) {
-                const int4 ab = F.cg4[foff + row];
-                if (ab.x >= 0) carry += C[3 * (size_t)ab.x + c];
-                if (ab.y >= 0) carry += C[3 * (size_t)ab.y + c];
-                if (ab.z >= 0) carry += C[3 * (size_t)ab.z + c];
-                if (ab.w >= 0) carry += C[3 * (size_t)ab.w + c];
-            } else {
-                for (int64_t g = F.cg_ptr[foff + row]; g < F.cg_ptr[foff + row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c];
-            }
-        }
+    if (CG2) {
+        int4 ab_c = F.cg4[foff + (pre_carry ? c_row : 0)];                        // (1)
+        int4 ab_t = F.cg4[foff + (pre_ts ? (int)threadIdx.x : 0)];
+        const double *src = y + 3 * (size_t)(first + (pre_ts ? (int)threadIdx.x : 0));
+        const double y0 = src[0], y1 = src[1], y2 = src[2];
+        if (!pre_carry) ab_c = make_int4(-1, -1, -1, -1);
+        if (!pre_ts) ab_t = make_int4(-1, -1, -1, -1);
+        const double cvx = C[3 * (size_t)max(ab_c.x, 0) + c_c], cvy = C[3 * (size_t)max(ab_c.y, 0) + c_c];      // (2)
+        const double *txp = C + 3 * (size_t)max(ab_t.x, 0), *typ = C + 3 * (size_t)max(ab_t.y, 0);
+        const double tx0 = txp[0], tx1 = txp[1], tx2 = txp[2], ty0 = typ[0], ty1 = typ[1], ty2 = typ[2];
+        carry += ab_c.x >= 0 ? cvx : 0.0; carry += ab_c.y >= 0 ? cvy : 0.0;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+        p0 += ab_t.x >= 0 ? tx0 : 0.0; p1 += ab_t.x >= 0 ? tx1 : 0.0; p2 += ab_t.x >= 0 ? tx2 : 0.0;
+        p0 += ab_t.y >= 0 ? ty0 : 0.0; p1 += ab_t.y >= 0 ? ty1 : 0.0; p2 += ab_t.y >= 0 ? ty2 : 0.0;
+        // (third and fourth slot: only under four-way tree nodes)
+        if (ab_c.z >= 0) carry += C[3 * (size_t)ab_c.z + c_c];
+        if (ab_c.w >= 0) carry += C[3 * (size_t)ab_c.w + c_c];
+        if (ab_t.z >= 0) { const double *c = C + 3 * (size_t)ab_t.z; p0 += c[0]; p1 += c[1]; p2 += c[2]; }
+        if (ab_t.w >= 0) { const double *c = C + 3 * (size_t)ab_t.w; p0 += c[0]; p1 += c[1]; p2 += c[2]; }
+        if (pre_ts) { ts[3 * threadIdx.x] = y0 - p0; ts[3 * threadIdx.x + 1] = y1 - p1; ts[3 * threadIdx.x + 2] = y2 - p2; }
+    } else if (pre_carry) {
+        for (int64_t g = F.cg_ptr[foff + c_row]; g < F.cg_ptr[foff + c_row + 1]; ++g) carry += C[3 * (size_t)F.cg_slot[g] + c_c];
     }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int c0 = 0; c0 < kneed; c0 += FWD_BIG_KCHUNK) {
@@ -438,20 +455,26 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
         const int jb = c0 + wave * per;
         int je = min(jb + per, c0 + kc);
         je = row_ok ? min(je, jend) : jb;
-        // first group of this wave's panel columns in flight before the staging barrier; after it the
-        // next group is always requested before the current one is consumed (two groups in flight)
         constexpr int D = ADMM_FWD_DEPTH;
         double cur[D], nxt[D];
-#pragma unroll
-        for (int q = 0; q < D; ++q) cur[q] = (jb + q < je) ? P[(size_t)f * (jb + q)] : 0.0;
-        __syncthreads();
-        for (int q = threadIdx.x; q < kc; q += NT) {
+        if (c0 > 0) __syncthreads();
+        // columns this thread did not stage ahead (k beyond one per thread; without the quadruple lists: all of them)
+        for (int q = (c0 == 0 && CG2) ? (int)threadIdx.x + NT : (int)threadIdx.x; q < kc; q += NT) {
             const double *src = y + 3 * (size_t)(first + c0 + q);
             double s0, s1, s2;
             child_sum<CG2>(F, foff + c0 + q, C, s0, s1, s2);
             ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
         }
-        __syncthreads();
+        // (3) first group of this wave's panel columns; after the barrier the next group is always requested before the current one
+        // is consumed (two groups in flight).  Unconditional loads: a column beyond the wave's range re-reads its last one, counts as 0.
+        {
+            const int jl = max(je - 1, 0);
+#pragma unroll
+            for (int q = 0; q < D; ++q) cur[q] = P[(size_t)f * min(jb + q, jl)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: the panel columns stay in flight
+#pragma unroll
+        for (int q = 0; q < D; ++q) cur[q] = (jb + q < je) ? cur[q] : 0.0;
         if (c0 == 0) ADMM_SWEEP_STAMP(1);
         for (int j = jb; j < je; j += D) {
 #pragma unroll
