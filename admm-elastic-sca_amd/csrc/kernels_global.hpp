@@ -351,21 +351,55 @@ __global__ __launch_bounds__(64 * ADMM_FWD_SMALL_WAVES) void solve_fwd_small_ker
     const bool row_ok = live && i < f;
     const double *P = F.panels + poff + (row_ok ? i : 0);
     const int jend = row_ok ? ((i < k) ? i + 1 : k) : 0;
+    // Same order as in the block kernel below: (1) both index quadruples (this lane's pass-through row, this lane's staged column) and
+    // the column's right-hand side; (2) the contribution values, first and second slot together; the staged vector goes to LDS;
+    // (3) only then the first group of panel columns.  The staged vector is private to the wave (ts[wave]): no workgroup barrier --
+    // LDS operations of one wave execute in order -- so nothing here waits for the panel columns or for the other waves.
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    if (row_ok && i >= k) child_sum<CG2>(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
-    // first group of panel columns in flight before the staging barrier; afterwards the next group is
-    // always requested before the current one is consumed
     constexpr int DS = ADMM_FWD_SMALL_DEPTH;
     double cur[DS], nxt[DS];
-#pragma unroll
-    for (int q = 0; q < DS; ++q) cur[q] = (q < jend) ? P[(size_t)f * q] : 0.0;
-    if (live && lane < k) {
-        const double *src = y + 3 * (size_t)(first + lane);
-        double s0, s1, s2;
-        child_sum<CG2>(F, foff + lane, C, s0, s1, s2);
-        ts[wave][3 * lane] = src[0] - s0; ts[wave][3 * lane + 1] = src[1] - s1; ts[wave][3 * lane + 2] = src[2] - s2;
+    const bool pass = row_ok && i >= k, stage = live && lane < k;
+    if (CG2) {
+        int4 ab_c = F.cg4[foff + (pass ? i : 0)];                                 // (1)
+        int4 ab_t = F.cg4[foff + (stage ? lane : 0)];
+        const double *src = y + 3 * (size_t)(first + (stage ? lane : 0));
+        const double y0 = src[0], y1 = src[1], y2 = src[2];
+        if (!pass) ab_c = make_int4(-1, -1, -1, -1);
+        if (!stage) ab_t = make_int4(-1, -1, -1, -1);
+        const double *cxp = C + 3 * (size_t)max(ab_c.x, 0), *cyp = C + 3 * (size_t)max(ab_c.y, 0);      // (2)
+        const double *txp = C + 3 * (size_t)max(ab_t.x, 0), *typ = C + 3 * (size_t)max(ab_t.y, 0);
+        const double cx0 = cxp[0], cx1 = cxp[1], cx2 = cxp[2], cy0 = cyp[0], cy1 = cyp[1], cy2 = cyp[2];
+        const double tx0 = txp[0], tx1 = txp[1], tx2 = txp[2], ty0 = typ[0], ty1 = typ[1], ty2 = typ[2];
+        c0 += ab_c.x >= 0 ? cx0 : 0.0; c1 += ab_c.x >= 0 ? cx1 : 0.0; c2 += ab_c.x >= 0 ? cx2 : 0.0;
+        c0 += ab_c.y >= 0 ? cy0 : 0.0; c1 += ab_c.y >= 0 ? cy1 : 0.0; c2 += ab_c.y >= 0 ? cy2 : 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        s0 += ab_t.x >= 0 ? tx0 : 0.0; s1 += ab_t.x >= 0 ? tx1 : 0.0; s2 += ab_t.x >= 0 ? tx2 : 0.0;
+        s0 += ab_t.y >= 0 ? ty0 : 0.0; s1 += ab_t.y >= 0 ? ty1 : 0.0; s2 += ab_t.y >= 0 ? ty2 : 0.0;
+        // (third and fourth slot: only under four-way tree nodes)
+        if (ab_c.z >= 0) { const double *c = C + 3 * (size_t)ab_c.z; c0 += c[0]; c1 += c[1]; c2 += c[2]; }
+        if (ab_c.w >= 0) { const double *c = C + 3 * (size_t)ab_c.w; c0 += c[0]; c1 += c[1]; c2 += c[2]; }
+        if (ab_t.z >= 0) { const double *c = C + 3 * (size_t)ab_t.z; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+        if (ab_t.w >= 0) { const double *c = C + 3 * (size_t)ab_t.w; s0 += c[0]; s1 += c[1]; s2 += c[2]; }
+        if (stage) { ts[wave][3 * lane] = y0 - s0; ts[wave][3 * lane + 1] = y1 - s1; ts[wave][3 * lane + 2] = y2 - s2; }
+    } else {
+        if (pass) child_sum<CG2>(F, foff + i, C, c0, c1, c2);   // pass-through of the children's rows beyond this supernode
+        if (stage) {
+            const double *src = y + 3 * (size_t)(first + lane);
+            double s0, s1, s2;
+            child_sum<CG2>(F, foff + lane, C, s0, s1, s2);
+            ts[wave][3 * lane] = src[0] - s0; ts[wave][3 * lane + 1] = src[1] - s1; ts[wave][3 * lane + 2] = src[2] - s2;
+        }
     }
-    __syncthreads();
+    // (3) first group of panel columns; afterwards the next group is always requested before the current one is consumed.
+    // Unconditional loads: a column beyond the row's range re-reads its last one and counts as zero.
+    {
+        const int jl = max(jend - 1, 0);
+#pragma unroll
+        for (int q = 0; q < DS; ++q) cur[q] = P[(size_t)f * min(q, jl)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own staged vector is in LDS (no workgroup barrier: ts[wave] is private)
+#pragma unroll
+    for (int q = 0; q < DS; ++q) cur[q] = (q < jend) ? cur[q] : 0.0;
     ADMM_SWEEP_STAMP(1);
     if (!row_ok) { ADMM_SWEEP_STAMP(2); return; }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
