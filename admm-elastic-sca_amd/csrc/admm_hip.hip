@@ -1313,18 +1313,18 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
             }
         }
     };
+    bool bad_pair = false;
     auto backward = [&](const std::vector<LevelDev> &levels, hipStream_t st) {
         for (int l = (int)levels.size() - 1; l >= 0; --l) {
             const LevelDev &L = levels[l];
             if (!L.n_bwd) continue;
-            if (L.bwd_cw == 4 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<4, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 4 && L.bwd_nw == 2) hipLaunchKernelGGL((solve_bwd_kernel<4, 2>), dim3(L.n_bwd), dim3(128), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 4) hipLaunchKernelGGL((solve_bwd_kernel<4>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 2 && L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<2, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_cw == 2) hipLaunchKernelGGL((solve_bwd_kernel<2>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_nw == 8) hipLaunchKernelGGL((solve_bwd_kernel<1, 8>), dim3(L.n_bwd), dim3(512), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else if (L.bwd_nw == 16) hipLaunchKernelGGL((solve_bwd_kernel<1, 16>), dim3(L.n_bwd), dim3(1024), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
-            else hipLaunchKernelGGL((solve_bwd_kernel<1>), dim3(L.n_bwd), dim3(256), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur);
+            // the level's work items were cut for bwd_nw * bwd_cw columns per block (upload_factor): the kernel must be THAT pair
+#define ADMM_BWD(CW, NWB) if (L.bwd_cw == CW && L.bwd_nw == NWB) { hipLaunchKernelGGL((solve_bwd_kernel<CW, NWB>), dim3(L.n_bwd), dim3(64 * NWB), 0, st, L.d_bwd, F, ctx->d_w, ctx->d_xcur); continue; }
+            ADMM_BWD(4, 2) ADMM_BWD(4, 4) ADMM_BWD(4, 8) ADMM_BWD(4, 16)
+            ADMM_BWD(2, 4) ADMM_BWD(2, 8) ADMM_BWD(2, 16)
+            ADMM_BWD(1, 4) ADMM_BWD(1, 8) ADMM_BWD(1, 16)
+#undef ADMM_BWD
+            bad_pair = true;
         }
     };
     const int n_side = (int)ctx->levels_side.size();
@@ -1367,6 +1367,7 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
     backward(ctx->levels, ctx->stream);
     TRY(join());
     HIPCHK(hipGetLastError());
+    if (bad_pair) return fail(ctx, ADMM_ERR_STATE, "backward sweep: no kernel for a level's (columns per wave, waves per block) pair");
     return ADMM_OK;
 }
 

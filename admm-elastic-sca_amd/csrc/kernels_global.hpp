@@ -502,7 +502,9 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
         // (3) first group of this wave's panel columns; after the barrier the next group is always requested before the current one
         // is consumed (two groups in flight).  Unconditional loads: a column beyond the wave's range re-reads its last one, counts as 0.
         {
-            const int jl = max(je - 1, 0);
+            // (a wave with no columns -- je == jb, possibly beyond k on a narrow supernode of a wide level -- re-reads column k - 1:
+            // every speculative address stays inside this supernode's panel)
+            const int jl = min(max(je - 1, 0), k - 1);
 #pragma unroll
             for (int q = 0; q < D; ++q) cur[q] = P[(size_t)f * min(jb + q, jl)];
         }

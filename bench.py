@@ -180,6 +180,7 @@ def install_rccl(s, torch, dist, rank, world, local_rank):
     if float(flag.item()) < 1.0:
         raise RuntimeError("ncclGetUniqueId failed on rank 0")
     state = {"ok": False, "cancel": False}
+    seen = 0
     lock = threading.Lock()
 
     def init():     # collective; the library selects the context's device before ncclCommInitRank
@@ -204,10 +205,12 @@ def install_rccl(s, torch, dist, rank, world, local_rank):
     good = float(flag.item()) >= 1.0
     if good:    # one checked all-reduce through the new communicator: 1 + 2 + ... + world
         probe = torch.full((8,), float(rank + 1), dtype=torch.float64, device=dev)
+        probe[4:] = 1.0                                 # second half: a head count of the ranks the communicator really joins
         torch.cuda.synchronize()
         try:
             s.debug_allreduce(probe.data_ptr(), probe.numel())
-            fine = bool((probe == world * (world + 1) / 2.0).all().item())
+            fine = bool((probe[:4] == world * (world + 1) / 2.0).all().item()) and bool((probe[4:] == float(world)).all().item())
+            seen = int(round(float(probe[4].item())))
         except Exception:  # noqa: BLE001
             fine = False
         flag.fill_(1.0 if fine else 0.0)
@@ -217,13 +220,42 @@ def install_rccl(s, torch, dist, rank, world, local_rank):
         if state["ok"]:
             s.set_rccl_comm(None)
         raise RuntimeError("in-library RCCL communicator unavailable on some rank (here: init ok = %r)" % (state["ok"],))
+    return seen
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process has not imported torch or touched a GPU
+    yet, so it starts the N ranks as a fresh child (`python -m torch.distributed.run`, one process per GPU, rendezvous on
+    127.0.0.1), relays the child's stdout (rank 0's JSON line) and stderr, and exits with the child's return code.  Never an
+    exec, never after a HIP call."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(int(os.environ.get("ADMM_BENCH_MASTER_PORT", "0")) or _free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    print("bench: --gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:8]) + " ... bench.py"), file=sys.stderr)
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:     # a silent 1-rank run under `--gpus 8` (or the reverse) would be reported as the wrong N
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -285,14 +317,21 @@ def main():
         # iteration takes at 8 GPUs -- and a Python hook re-enters the interpreter every iteration.  The communicator is
         # bootstrapped through the torch process group; any failure (on any rank) makes ALL ranks fall back to the torch hook.
         s.set_allreduce(torch_hook)
-        comm_path = "torch.distributed.all_reduce (hook)"
+        comm_path = "torch.distributed.all_reduce (hook, backend %s)" % backend
+        ranks_seen = None
         if backend == "nccl" and os.environ.get("ADMM_BENCH_TORCH_ALLREDUCE") != "1":
             try:
-                install_rccl(s, torch, dist, rank, world if not fake_dist else 1, local_rank)
+                ranks_seen = install_rccl(s, torch, dist, rank, world if not fake_dist else 1, local_rank)
                 comm_path = "ncclAllReduce inside libadmm_hip.so"
             except Exception as e:  # noqa: BLE001
                 if rank == 0:
                     print("bench: in-library RCCL unavailable (%r), using torch.distributed" % (e,), file=sys.stderr)
+        if ranks_seen is None:       # the hook path: the same head count through the process group the hook uses
+            ones = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+            ranks_seen = int(round(float(ones.item())))
+        if ranks_seen != (world if not fake_dist else 1):      # an N-rank launch whose collective joins fewer ranks is not an N-GPU run
+            raise SystemExit("bench.py: rank %d: the all-reduce path joins %d ranks, expected %d" % (rank, ranks_seen, world))
     s.initialize()
     t_init = time.time() - t0
     info = s.info()
@@ -401,6 +440,8 @@ def main():
         dist.all_gather(allr, mine)
         out["per_rank"] = {k: [round(float(t[i]), 4) for t in allr] for i, k in enumerate(keys)}
         out["per_rank"]["elements"] = [int(t[len(keys)]) for t in allr]
+        out["rccl_ranks_seen"] = ranks_seen              # head count from a checked all-reduce through the path config.allreduce names
+        out["ranks_ok"] = bool(ranks_seen == a.gpus == world)
     if rank == 0 and world == 1 and fake_world <= 1 and not a.no_extras:
         # what an existing scene pays per frame through the class API (host/admm/System.hpp step(): m_x / m_v are public, so they
         # travel every frame): the same C-ABI sequence, upload_state -> step -> download_state, on page-locked vectors

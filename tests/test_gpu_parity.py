@@ -226,6 +226,36 @@ def test_solve_residual_and_vs_oracle(pkg, monkeypatch, dense_max, leaf):
     assert np.array_equal(s.solve_only(b), s.solve_only(b))
 
 
+@pytest.mark.parametrize("nw,cw2,small_nw", [("16", True, "4"), ("16", False, "8"), ("8", True, "2"), ("4", True, "4"), ("4", False, "4")])
+def test_backward_kernel_shapes(pkg, monkeypatch, nw, cw2, small_nw):
+    """Every (columns per wave, waves per block) pair the documented knobs can produce has a kernel: the level's work items
+    are cut for bwd_nw * bwd_cw columns per block and the dispatch must launch exactly that instantiation (a missing branch
+    used to fall through to a narrower kernel and leave columns of x unwritten -- ADVICE r2).  A x = b with the knobs forced
+    onto every level of a bar with wide and narrow supernodes, and the default shapes' solution to rounding."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "64")
+    dims = (12, 12, 30)
+    ref = pkg.make_bar_system(*dims, device_id=0); ref.initialize()
+    monkeypatch.setenv("ADMM_HIP_BWD_NW", nw)
+    monkeypatch.setenv("ADMM_HIP_BWD_NW_MIN_COLS", "0")
+    monkeypatch.setenv("ADMM_HIP_BWD_SMALL_NW", small_nw)
+    if cw2:
+        monkeypatch.setenv("ADMM_HIP_BWD_CW2_MIN", "1"); monkeypatch.setenv("ADMM_HIP_BWD_CW2_MAX", "100000000")
+    else:
+        monkeypatch.setenv("ADMM_HIP_BWD_CW2_MIN", "0")
+    s = pkg.make_bar_system(*dims, device_id=0); s.initialize()
+    n = s.n_nodes
+    rng = np.random.default_rng(11)
+    for _ in range(2):
+        b = rng.normal(size=3 * n)
+        x = s.solve_only(b)
+        assert np.isfinite(x).all()
+        assert np.abs(s.apply_A(x) - b).max() < 1e-11 * np.abs(b).max()
+        # (not bitwise the default shapes' result: a block's first column decides which lane sums which rows)
+        assert np.abs(x - ref.solve_only(b)).max() < 1e-12 * np.abs(x).max()
+        assert np.array_equal(x, s.solve_only(b))
+
+
 @pytest.mark.parametrize("dims,leaf", [((6, 5, 17), "16"), ((8, 8, 40), "0"), ((12, 12, 30), "64")])
 def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
     """The numeric multifrontal factorization on the GPU (csrc/factor_dev.hpp: MFMA fp64 products per 64-column block, block

@@ -352,18 +352,57 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     one = json.loads(r1.stdout.strip().splitlines()[-1])
     env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                         os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    # PLAIN `python bench.py --gpus 2`: bench.py starts its two ranks itself (a fresh torch.distributed.run child, before
+    # anything touches the GPU) and relays rank 0's line and the return code
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr[-3000:]
     lines = [l for l in r2.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0 and "cpu_baseline" not in two
+    assert two["rccl_ranks_seen"] == 2 and two["ranks_ok"] is True and "gloo" in two["config"]["allreduce"]
+    # ... and as the driver launches it (torch.distributed.run around bench.py): same line
+    r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                         os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    three = json.loads([l for l in r3.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert three["n_gpus"] == 2 and three["config"]["x_checksum"] == two["config"]["x_checksum"]
     assert two["config"]["parallelism"].startswith("x2: elements and elimination subtrees")
     pr = two["per_rank"]                                       # per-rank phase times and element counts travel with the line
     assert len(pr["local_ms"]) == 2 and min(pr["total_ms"]) > 0 and sum(pr["elements"]) == 8 * 8 * 40 * 6 + 9 * 9
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """`--gpus N` must describe the launch: a launcher that started another number of ranks is an error, not a silently
+    mislabelled run (no torch import, no GPU needed for the check)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    env = dict(os.environ, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_bench_self_launch_relays_the_childs_failure():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks; in the GPU-less build container both ranks refuse
+    to run ("needs an MI355X", no CPU fallback) and the parent must hand that failure on as a non-zero exit code."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("build-container check (on a GPU box the ranks would run the full-size bench)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "starting -m torch.distributed.run" in r.stderr and "needs an MI355X" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def _spring_net(n=9, h=0.1):
