@@ -38,6 +38,7 @@ struct Batch {
     std::vector<double> targets;   // anchors [n_total][3]
     bool moving = false;
     std::vector<int32_t> active;   // anchors [n_total]
+    double *h_tg = nullptr; int32_t *h_ac = nullptr; hipEvent_t upd_ev = nullptr;   // anchors: pinned staging of this rank's targets / flags + "last update has left it"
     // finalize
     std::vector<double> weight, rest, measure;  // [n_total], [n_total][12], [n_total]
     std::vector<int32_t> global_idx;             // compact first row
@@ -102,6 +103,8 @@ struct admm_hip_ctx {
     int rank = 0, world = 1;
     admm_hip_allreduce_fn allreduce = nullptr; void *allreduce_user = nullptr;
     void *rccl_comm = nullptr; bool rccl_owned = false;      // ncclComm_t: the all-reduce is ncclAllReduce on the context's stream (takes precedence over the hook)
+    admm_hip_host_allreduce_fn host_allreduce = nullptr; void *host_allreduce_user = nullptr;   // transport that sums HOST buffers (admm_hip_set_host_allreduce)
+    double *h_comm = nullptr; size_t h_comm_cap = 0;          // its pinned staging
     bool finalized = false;
     int leaf_size = 0;                        // nested-dissection leaf size; 0 = by system size (host_factor)
     // host state
@@ -263,6 +266,12 @@ void free_device(admm_hip_ctx *ctx) {
     if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
+    for (Batch &b : ctx->batches) {
+        if (b.h_tg) (void)hipHostFree(b.h_tg);
+        if (b.h_ac) (void)hipHostFree(b.h_ac);
+        if (b.upd_ev) (void)hipEventDestroy(b.upd_ev);
+        b.h_tg = nullptr; b.h_ac = nullptr; b.upd_ev = nullptr;
+    }
     ctx->levels.clear(); ctx->levels_side.clear(); ctx->levels_gtop.clear();
 }
 
@@ -1550,6 +1559,7 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         if (ctx->rccl_comm && ctx->rccl_owned) { RcclApi *R = rccl_api(nullptr); if (R) (void)R->CommDestroy(ctx->rccl_comm); }
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
+        if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
         for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         for (hipEvent_t e : ctx->ev_join) (void)hipEventDestroy(e);
@@ -1767,6 +1777,31 @@ int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *us
     return ADMM_OK;
 }
 
+// transports that only see host memory (MPI without GPU support, shared memory between the ranks of a node): the buffer is
+// staged through pinned host memory around the caller's function
+static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, void *hip_stream) {
+    admm_hip_ctx *ctx = (admm_hip_ctx *)self;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!ctx->host_allreduce) return 1;
+    if ((size_t)count > ctx->h_comm_cap) {
+        if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        ctx->h_comm = nullptr; ctx->h_comm_cap = 0;
+        if (hipHostMalloc((void **)&ctx->h_comm, sizeof(double) * (size_t)count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        ctx->h_comm_cap = (size_t)count;
+    }
+    const size_t bytes = sizeof(double) * (size_t)count;
+    if (hipMemcpyAsync(ctx->h_comm, dev_buf, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+    if (ctx->host_allreduce(ctx->host_allreduce_user, ctx->h_comm, count) != 0) return 1;
+    if (hipMemcpyAsync(dev_buf, ctx->h_comm, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+    return 0;
+}
+int admm_hip_set_host_allreduce(admm_hip_ctx *ctx, admm_hip_host_allreduce_fn fn, void *user) {
+    if (!ctx) return ADMM_ERR_ARG;
+    ctx->host_allreduce = fn; ctx->host_allreduce_user = user;
+    ctx->allreduce = fn ? host_allreduce_trampoline : nullptr; ctx->allreduce_user = fn ? ctx : nullptr;
+    return ADMM_OK;
+}
+
 int admm_hip_rccl_unique_id(void *id128) {
     if (!id128) return ADMM_ERR_ARG;
     std::string why;
@@ -1874,12 +1909,18 @@ int admm_hip_update_anchors(admm_hip_ctx *ctx, int batch, const double *targets,
     if (targets) std::copy(targets, targets + (size_t)3 * b.n_total, b.targets.begin());
     if (active) std::copy(active, active + b.n_total, b.active.begin());
     if (ctx->finalized && ctx->device_id >= 0 && b.n_local) {
+        // asynchronous on the context's stream (it is ordered before the next step's kernels): this rank's targets / flags go
+        // through a pinned staging buffer owned by the batch; the only wait is for the PREVIOUS update to have left that buffer
         HIPCHK(hipSetDevice(ctx->device_id));
-        std::vector<double> tg(3 * (size_t)b.n_local); std::vector<int32_t> ac(b.n_local);
-        for (int el = 0; el < b.n_local; ++el) { for (int j = 0; j < 3; ++j) tg[3 * (size_t)el + j] = b.targets[3 * (size_t)b.local[el] + j]; ac[el] = b.active[b.local[el]]; }
-        if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, tg.data(), sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
-        if (active) HIPCHK(hipMemcpyAsync(b.d_active, ac.data(), sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!b.h_tg) {
+            HIPCHK(hipHostMalloc((void **)&b.h_tg, sizeof(double) * 3 * (size_t)b.n_local, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&b.h_ac, sizeof(int32_t) * (size_t)b.n_local, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&b.upd_ev, hipEventDisableTiming));
+        } else HIPCHK(hipEventSynchronize(b.upd_ev));
+        for (int el = 0; el < b.n_local; ++el) { for (int j = 0; j < 3; ++j) b.h_tg[3 * (size_t)el + j] = b.targets[3 * (size_t)b.local[el] + j]; b.h_ac[el] = b.active[b.local[el]]; }
+        if (targets) HIPCHK(hipMemcpyAsync(b.d_targets, b.h_tg, sizeof(double) * 3 * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        if (active) HIPCHK(hipMemcpyAsync(b.d_active, b.h_ac, sizeof(int) * b.n_local, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipEventRecord(b.upd_ev, ctx->stream));
     }
     return ADMM_OK;
 }
@@ -2049,8 +2090,10 @@ int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on) {
     if (!ctx || !p) return ADMM_ERR_ARG;
     if (ctx->device_id < 0) return ADMM_OK;
     HIPCHK(hipSetDevice(ctx->device_id));
-    if (on) HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
-    else HIPCHK(hipHostUnregister(p));
+    // a refused registration is not an error of the solver (pageable memory works, only slower): report it, clear HIP's
+    // sticky last-error so that no later hipGetLastError() check trips over it, leave last_error alone
+    const hipError_t e = on ? hipHostRegister(p, bytes, hipHostRegisterDefault) : hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ADMM_ERR_HIP; }
     return ADMM_OK;
 }
 int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v) {

@@ -1,0 +1,161 @@
+// Comm.hpp -- what a C++ host needs to run one admm::System per GPU (one process per rank).
+//
+// The reference is single-process (System.cpp:57-58 is an OpenMP loop); here the element loop of
+// System::step shards across ranks and the partial right-hand sides meet in one all-reduce per ADMM
+// iteration.  The all-reduce itself is RCCL inside libadmm_hip.so
+// (admm_hip_rccl_init); a communicator needs ONE 128-byte id to travel from rank 0 to the other ranks
+// before it exists, and a C++ host has no torch process group for that.  Two helpers, plain POSIX:
+//
+//   rccl_id_via_file   rank 0 publishes the ncclUniqueId in a file (written under a temporary name,
+//                      renamed into place), the other ranks wait for it.  Works across nodes on a
+//                      shared filesystem.  The path must be unique per job (e.g. contain the job id).
+//   ShmAllReduce       a host-memory all-reduce between the ranks of ONE node through a POSIX shared
+//                      memory segment (sums in rank order: every rank gets the same bits).  Not the
+//                      production transport -- RCCL over xGMI is -- but it needs no RCCL, so several
+//                      ranks can share one GPU (RCCL refuses that): bring-up and the tests use it via
+//                      admm_hip_set_host_allreduce.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace admm {
+namespace comm {
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// rank 0: id holds the 128 bytes to publish; other ranks: id receives them.  false + *why on failure / timeout.
+// A file older than max_age_s is taken for a leftover of an earlier job and ignored (the wait goes on).
+inline bool rccl_id_via_file(const std::string &path, int rank, unsigned char id[128], double timeout_s, double max_age_s, std::string *why) {
+    if (path.empty()) { if (why) *why = "no rendezvous file given"; return false; }
+    if (rank == 0) {
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        FILE *f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, 128, f) != 128) { if (f) std::fclose(f); if (why) *why = "cannot write " + tmp; return false; }
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) { if (why) *why = "cannot rename " + tmp + " to " + path; return false; }
+        return true;
+    }
+    const double t0 = now_s();
+    for (;;) {
+        struct stat st;
+        if (::stat(path.c_str(), &st) == 0 && st.st_size == 128 && (max_age_s <= 0.0 || std::difftime(::time(nullptr), st.st_mtime) <= max_age_s)) {
+            FILE *f = std::fopen(path.c_str(), "rb");
+            if (f) {
+                const size_t got = std::fread(id, 1, 128, f);
+                std::fclose(f);
+                if (got == 128) return true;
+            }
+        }
+        if (now_s() - t0 > timeout_s) { if (why) *why = "timed out waiting for rank 0's id in " + path; return false; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+}
+
+class ShmAllReduce {
+public:
+    ShmAllReduce() : rank_(0), world_(1), cap_(0), hdr_(nullptr), data_(nullptr), bytes_(0), sense_(0), timeout_s_(120.0) {}
+    ~ShmAllReduce() { close(); }
+    ShmAllReduce(const ShmAllReduce &) = delete;
+    ShmAllReduce &operator=(const ShmAllReduce &) = delete;
+
+    // name: "/something-unique-per-job"; capacity: doubles per rank and round (longer buffers go in rounds)
+    bool open(const std::string &name, int rank, int world, size_t capacity = (size_t)1 << 20, double timeout_s = 120.0) {
+        close();
+        rank_ = rank; world_ = world; cap_ = capacity; timeout_s_ = timeout_s; name_ = name;
+        bytes_ = sizeof(Header) + sizeof(double) * cap_ * (size_t)world_;
+        int fd = -1;
+        if (rank == 0) {
+            ::shm_unlink(name.c_str());
+            fd = ::shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ::ftruncate(fd, (off_t)bytes_) != 0) { if (fd >= 0) ::close(fd); return false; }
+        } else {
+            const double t0 = now_s();
+            for (;;) {
+                fd = ::shm_open(name.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (fd >= 0 && ::fstat(fd, &st) == 0 && (size_t)st.st_size == bytes_) break;
+                if (fd >= 0) { ::close(fd); fd = -1; }
+                if (now_s() - t0 > timeout_s) return false;
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        void *p = ::mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        hdr_ = static_cast<Header *>(p);
+        data_ = reinterpret_cast<double *>(static_cast<char *>(p) + sizeof(Header));
+        if (rank == 0) {
+            hdr_->count.store(0); hdr_->sense.store(0); hdr_->failed.store(0); hdr_->world = world;
+            hdr_->magic.store(kMagic, std::memory_order_release);
+        } else {
+            const double t0 = now_s();
+            while (hdr_->magic.load(std::memory_order_acquire) != kMagic) {
+                if (now_s() - t0 > timeout_s) return false;
+                std::this_thread::yield();
+            }
+            if (hdr_->world != world) return false;
+        }
+        const bool ok = barrier();       // everybody has mapped the segment: the name can go (nothing is left behind by a crash)
+        if (rank == 0) ::shm_unlink(name.c_str());
+        return ok;
+    }
+    void close() {
+        if (hdr_) { ::munmap(hdr_, bytes_); hdr_ = nullptr; data_ = nullptr; }
+    }
+    // buf[0..count) <- sum over the ranks, added in rank order on every rank (bitwise the same everywhere)
+    bool allreduce(double *buf, int64_t count) {
+        if (!hdr_) return false;
+        for (int64_t off = 0; off < count; off += (int64_t)cap_) {
+            const size_t n = (size_t)((count - off < (int64_t)cap_) ? count - off : (int64_t)cap_);
+            std::memcpy(data_ + cap_ * (size_t)rank_, buf + off, sizeof(double) * n);
+            if (!barrier()) return false;
+            for (size_t i = 0; i < n; ++i) {
+                double s = data_[i];
+                for (int r = 1; r < world_; ++r) s += data_[cap_ * (size_t)r + i];
+                buf[off + i] = s;
+            }
+            if (!barrier()) return false;       // nobody overwrites its slot before everybody has read it
+        }
+        return true;
+    }
+    // admm_hip_host_allreduce_fn
+    static int hook(void *self, double *host_buf, int64_t count) { return static_cast<ShmAllReduce *>(self)->allreduce(host_buf, count) ? 0 : 1; }
+
+private:
+    static constexpr uint32_t kMagic = 0xADB17E55u;
+    struct Header { std::atomic<uint32_t> magic; std::atomic<int> count, sense, failed; int world; char pad[44]; };
+    int rank_, world_; size_t cap_; Header *hdr_; double *data_; size_t bytes_; int sense_; double timeout_s_; std::string name_;
+
+    // sense-reversing barrier; a rank that gives up (a peer died) marks the segment failed so that the others give up too
+    bool barrier() {
+        sense_ ^= 1;
+        if (hdr_->count.fetch_add(1, std::memory_order_acq_rel) == world_ - 1) {
+            hdr_->count.store(0, std::memory_order_relaxed);
+            hdr_->sense.store(sense_, std::memory_order_release);
+            return hdr_->failed.load() == 0;
+        }
+        const double t0 = now_s();
+        unsigned spins = 0;
+        while (hdr_->sense.load(std::memory_order_acquire) != sense_) {
+            if (hdr_->failed.load(std::memory_order_relaxed)) return false;
+            if ((++spins & 1023u) == 0) {
+                if (now_s() - t0 > timeout_s_) { hdr_->failed.store(1); return false; }
+                std::this_thread::yield();
+            }
+        }
+        return hdr_->failed.load() == 0;
+    }
+};
+
+} // namespace comm
+} // namespace admm

@@ -18,6 +18,7 @@
 // A user-written ExplicitForce::project runs here at the start of step().
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <iostream>
@@ -26,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include "Comm.hpp"
 #include "Force.hpp"
 #include "admm_hip.h"
 
@@ -33,7 +35,7 @@ namespace admm {
 
 class System {
 public:
-    System() : elapsed_s(0.0), device_id(0), initialized(false), gpu(nullptr), user_rows(0), pinned_x(nullptr), pinned_v(nullptr), seen_x(nullptr), seen_v(nullptr), pinned_bytes(0) {}
+    System() : elapsed_s(0.0), device_id(0), initialized(false), gpu(nullptr), user_rows(0), pinned_x(nullptr), pinned_v(nullptr), seen_x(nullptr), seen_v(nullptr), pinned_bytes(0), init_count(0) {}
     ~System() { release(); }
     System(const System &) = delete;
     System &operator=(const System &) = delete;
@@ -71,9 +73,48 @@ public:
     std::vector<std::function<void(System *)> > pre_step_callbacks;
     int device_id;                 // HIP device of this System (one process per GPU)
 
+    // Multi-GPU (no reference counterpart: the reference's element loop, System.cpp:57-58, is one OpenMP team).  One process
+    // per GPU, every process builds the SAME System (all nodes, all forces, same order) and sets its rank before initialize():
+    // the elements shard across the ranks, the partial right-hand sides meet in one all-reduce per ADMM iteration inside the
+    // library, and m_x / m_v are complete on every rank after every step().  Pre-step callbacks, control points and
+    // recompute_weights() must run identically on all ranks.
+    struct Shard {
+        int rank, world;
+        int mode;                        // ADMM_SHARD_SUBTREE (default: ranks own elimination subtrees, small exchange) or ADMM_SHARD_CONTIGUOUS
+        // RCCL (default transport): rank 0 publishes the communicator's 128-byte id in this file, the others wait for it
+        // (Comm.hpp rccl_id_via_file; a path unique to the job, on a filesystem all ranks see)
+        std::string rccl_id_file;
+        double rendezvous_timeout_s, rendezvous_max_age_s;
+        // any other transport instead: a hook that sums a DEVICE buffer (admm_hip_set_allreduce) or a HOST buffer
+        // (admm_hip_set_host_allreduce, e.g. comm::ShmAllReduce::hook) in place across the ranks
+        admm_hip_allreduce_fn allreduce; void *allreduce_user;
+        admm_hip_host_allreduce_fn host_allreduce; void *host_allreduce_user;
+        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(120.0), rendezvous_max_age_s(600.0),
+                  allreduce(nullptr), allreduce_user(nullptr), host_allreduce(nullptr), host_allreduce_user(nullptr) {}
+        // what a launcher exports: torchrun / torch.distributed.run (RANK, WORLD_SIZE, LOCAL_RANK), Open MPI, Slurm;
+        // ADMM_HIP_RCCL_ID_FILE names the rendezvous file.  Returns the local rank (the caller's device_id), or -1 if no launcher is seen.
+        int from_env() {
+            static const char *const rk[] = {"RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"}, *const wd[] = {"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"},
+                              *const lr[] = {"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"};
+            for (int i = 0; i < 3; ++i) {
+                const char *r = std::getenv(rk[i]), *w = std::getenv(wd[i]), *l = std::getenv(lr[i]);
+                if (!r || !w) continue;
+                rank = std::atoi(r); world = std::atoi(w);
+                if (const char *f = std::getenv("ADMM_HIP_RCCL_ID_FILE")) rccl_id_file = f;
+                else if (rccl_id_file.empty()) {      // per job: the launcher's rendezvous port / job id tells two jobs on one node apart
+                    const char *tag = std::getenv("MASTER_PORT"); if (!tag) tag = std::getenv("SLURM_JOB_ID"); if (!tag) tag = std::getenv("OMPI_MCA_ess_base_jobid");
+                    rccl_id_file = std::string("/tmp/admm_hip_rccl_id.") + std::to_string((long)getuid()) + "." + (tag ? tag : "0");
+                }
+                return l ? std::atoi(l) : rank;
+            }
+            return -1;
+        }
+    } shard;
+
     // System.cpp:78-95
     int add_nodes(VectorXd x, VectorXd m) {
         const int old_n = (int)m_x.size(), add = (int)x.size();
+        unpin_state();             // the vectors are about to be re-allocated: never leave a freed buffer page-locked
         m_x.conservativeResize(old_n + add); m_v.conservativeResize(old_n + add); m_masses.conservativeResize(old_n + add);
         for (int i = 0; i < add; ++i) { m_x[old_n + i] = x[i]; m_v[old_n + i] = 0.0; m_masses[old_n + i] = m[i]; }
         return (old_n + add) / 3;
@@ -88,11 +129,12 @@ public:
             settings.timestep_s = 0.04;
         }
         if (!(m_masses.size() == m_x.size() && m_x.size() >= 3)) { std::cerr << "\n**Solver Error: Problem with node data!" << std::endl; return false; }
+        release();                  // (also un-pins m_x / m_v before they may be re-allocated)
         if (m_v.size() < m_x.size()) m_v.resize(m_x.size());
         m_v.setZero();
-        release();
         if (admm_hip_create(&gpu, device_id) != ADMM_OK) { std::cerr << "\n**Solver Error: no usable HIP device " << device_id << " (the built-in forces have no CPU path)" << std::endl; gpu = nullptr; return false; }
         if (!check(admm_hip_set_timestep(gpu, settings.timestep_s))) return false;
+        if (!setup_shard()) return false;
         if (!check(admm_hip_add_nodes(gpu, dof / 3, m_x.data(), m_masses.data(), nullptr))) return false;
         // Force::initialize of the user-written forces (System.cpp:117-119); the built-in ones compute their rest data in the library
         for (size_t i = 0; i < forces.size(); ++i) {
@@ -203,7 +245,8 @@ public:
         for (size_t cb = 0; cb < pre_step_callbacks.size(); ++cb) pre_step_callbacks[cb](this);
         // host-mutable parameters: control points, explicit-force directions
         for (size_t b = 0; b < batch_first.size(); ++b) if (batch_moving[b]) {
-            std::vector<double> tgt((size_t)batch_count[b] * 3); std::vector<int32_t> act(batch_count[b]);
+            std::vector<double> &tgt = anchor_tgt; std::vector<int32_t> &act = anchor_act;      // members: no allocation per frame
+            tgt.resize((size_t)batch_count[b] * 3); act.resize(batch_count[b]);
             for (int e = 0; e < batch_count[b]; ++e) {
                 const MovingAnchor *ma = static_cast<const MovingAnchor *>(forces[batch_first[b] + e].get());
                 for (int c = 0; c < 3; ++c) tgt[3 * (size_t)e + c] = ma->point->pos[c];
@@ -231,7 +274,18 @@ public:
             bool any_released = false;
             for (int e = 0; e < batch_count[b] && !any_released; ++e) any_released = !static_cast<MovingAnchor *>(forces[batch_first[b] + e].get())->point->active;
             if (!any_released) continue;
-            std::vector<double> tgt((size_t)batch_count[b] * 3);
+            if (shard.world > 1) {
+                // sharded: a rank holds the projection state of its own anchors only; every rank takes the node's position
+                // after the frame instead (the value the next frame's first Dx would give), so the control points stay
+                // identical on all ranks
+                for (int e = 0; e < batch_count[b]; ++e) {
+                    MovingAnchor *ma = static_cast<MovingAnchor *>(forces[batch_first[b] + e].get());
+                    if (!ma->point->active) for (int c = 0; c < 3; ++c) ma->point->pos[c] = m_x[3 * (size_t)ma->idx + c];
+                }
+                continue;
+            }
+            std::vector<double> &tgt = anchor_tgt;
+            tgt.resize((size_t)batch_count[b] * 3);
             if (!check(admm_hip_read_local(gpu, (int)b, nullptr, nullptr, tgt.data(), nullptr))) return false;
             for (int e = 0; e < batch_count[b]; ++e) {
                 MovingAnchor *ma = static_cast<MovingAnchor *>(forces[batch_first[b] + e].get());
@@ -276,6 +330,31 @@ protected:
     std::vector<int> user_local;
     VectorXd user_Dx, user_u, user_z;
     void *pinned_x, *pinned_v, *seen_x, *seen_v; size_t pinned_bytes;
+    std::vector<double> anchor_tgt; std::vector<int32_t> anchor_act;     // step(): this frame's control points
+    int init_count;                        // initialize() calls so far (every rank counts alike: part of the rendezvous file's name)
+
+    // world > 1: hand rank / world / mode to the library and install the all-reduce -- a caller's hook, or (default) an RCCL
+    // communicator inside the library, its id bootstrapped through shard.rccl_id_file
+    bool setup_shard() {
+        ++init_count;
+        if (shard.world <= 1) return true;
+        if (shard.rank < 0 || shard.rank >= shard.world) { std::cerr << "\n**Solver Error: shard.rank " << shard.rank << " outside [0, " << shard.world << ")" << std::endl; return false; }
+        if (!check(admm_hip_set_shard(gpu, shard.rank, shard.world)) || !check(admm_hip_set_shard_mode(gpu, shard.mode))) return false;
+        if (shard.host_allreduce) return check(admm_hip_set_host_allreduce(gpu, shard.host_allreduce, shard.host_allreduce_user));
+        if (shard.allreduce) return check(admm_hip_set_allreduce(gpu, shard.allreduce, shard.allreduce_user));
+        unsigned char id[128];
+        std::memset(id, 0, sizeof id);
+        if (shard.rank == 0 && !check(admm_hip_rccl_unique_id(id))) return false;
+        const std::string file = shard.rccl_id_file.empty() ? std::string() : shard.rccl_id_file + "." + std::to_string(init_count);
+        std::string why;
+        if (!comm::rccl_id_via_file(file, shard.rank, id, shard.rendezvous_timeout_s, shard.rendezvous_max_age_s, &why)) {
+            std::cerr << "\n**Solver Error: multi-GPU rendezvous failed: " << why << " (set System::shard.rccl_id_file, or install an all-reduce hook)" << std::endl;
+            return false;
+        }
+        const bool ok = check(admm_hip_rccl_init(gpu, id, shard.rank, shard.world));     // collective: returns once every rank has joined
+        if (shard.rank == 0) std::remove(file.c_str());
+        return ok;
+    }
 
     // Force::project for every user force of this rank (System.cpp:57-58), on the rows the library hands over
     static int project_hook(void *self_, double dt, int64_t n_rows, const double *Dx, double *u, double *z) {

@@ -127,6 +127,11 @@ int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t
 typedef int (*admm_hip_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *hip_stream);
 int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world);
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user);
+/* Transports that only see HOST memory (MPI without GPU support, shared memory between the ranks of one node -- see
+ * host/admm/Comm.hpp ShmAllReduce): the library stages the buffer through pinned host memory around fn, which must sum
+ * host_buf[0..count) in place across the ranks.  Replaces any device hook; NULL removes it.                          */
+typedef int (*admm_hip_host_allreduce_fn)(void *user, double *host_buf, int64_t count);
+int admm_hip_set_host_allreduce(admm_hip_ctx *ctx, admm_hip_host_allreduce_fn fn, void *user);
 /* RCCL inside the library (north_star: "host stays C++"): with a communicator installed the per-iteration exchange is
  * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, <the context's stream>) issued by the step loop itself -- no
  * host hook between the kernels, and (ADMM_HIP_GRAPH_COMM=1) the whole multi-GPU iteration replays as one HIP graph.
@@ -199,6 +204,8 @@ int admm_hip_set_v(admm_hip_ctx *ctx, const double *v);
  * returns when both vectors have arrived.  One DMA per vector straight from / into the caller's memory; the
  * reordering to the factor's node order runs on the device.  admm_hip_pin_host page-locks (on = 1) or releases
  * (on = 0) a caller buffer so that these DMAs run at full PCIe rate without a staging copy.                      */
+/* (a refused registration returns ADMM_ERR_HIP without touching last_error or HIP's sticky error: the caller may go on
+ * with pageable memory)                                                                                               */
 int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on);
 int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v);
 int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v);

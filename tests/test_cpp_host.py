@@ -35,7 +35,7 @@ def have_gpu():
 
 
 def test_compiles_and_fails_loudly_without_gpu(pkg):
-    for name in ("singletet", "singlenode", "scene_bar", "scene_plinko", "user_force", "dillo_main"):
+    for name in ("singletet", "singlenode", "scene_bar", "scene_ranks", "scene_plinko", "user_force", "dillo_main"):
         exe = compile_cpp(name, pkg)
         assert os.path.exists(exe)
     if have_gpu():
@@ -105,6 +105,78 @@ def test_scene_through_class_api(pkg, tmp_path, typ):
         o.step(); elapsed += 0.04
         assert np.abs(X[fr] - o.x).max() < 2e-4, fr       # within the truncated-prox sensitivity
     assert np.abs(cp_final - np.array(list(o.force(h).pos))).max() < 2e-4
+
+
+def test_comm_helpers_on_the_cpu(pkg, tmp_path):
+    """host/admm/Comm.hpp without a GPU: the shared-memory all-reduce between three processes (every rank gets the sum added
+    in rank order, bit for bit, also when the buffer needs several rounds through the segment) and the rendezvous file that
+    carries the RCCL id from rank 0 to the others (atomic publish, waiting reader, leftovers of earlier jobs ignored)."""
+    exe = compile_cpp("comm_check", pkg)
+    name = "/admm_comm_check_%d" % os.getpid()
+    ps = [subprocess.Popen([exe, "shm", name, str(r), "3", "5000", "1024"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    assert len({o[0] for o in outs}) == 1 and outs[0][0].startswith("ok ")
+    idf = str(tmp_path / "rccl_id")
+    reader = subprocess.Popen([exe, "file", idf, "1"], stdout=subprocess.PIPE, text=True)          # waits for rank 0
+    writer = subprocess.run([exe, "file", idf, "0"], capture_output=True, text=True, timeout=60)
+    assert writer.returncode == 0 and reader.communicate(timeout=60)[0] == writer.stdout and writer.stdout.startswith("ok ")
+    old = os.path.getmtime(idf) - 7200
+    os.utime(idf, (old, old))                                                                    # a leftover of an earlier job
+    stale = subprocess.run([exe, "file", idf, "1", "600"], capture_output=True, text=True, timeout=60)
+    assert stale.returncode == 5 and "timed out" in stale.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, 1), (3, 1), (2, 0)])
+def test_scene_through_class_api_multi_rank(pkg, tmp_path, world, mode):
+    """Multi-GPU from the C++ class API (System::shard; System.hpp:29-76 has no counterpart -- the reference's element loop is
+    one OpenMP team, System.cpp:57-58): `world` PROCESSES each build the whole scene of scene_bar.cpp and own a shard of its
+    elements (mode 1: elimination subtrees, 0: contiguous ranges); on this one-GPU box they share the GPU and meet in
+    comm::ShmAllReduce instead of RCCL.  Every rank ends every frame with the complete, identical m_x, equal to the
+    single-process run up to the order of the partial sums."""
+    mg = pkg.meshgen
+    dims = (8, 8, 40)                    # 3321 nodes: beyond the explicit-inverse solve, so the subtree split is real
+    x, t = mg.bar(*dims)
+    m = mg.lumped_tet_mass(x, t, 1000.0)
+    anchors = mg.bar_anchor_nodes(dims[0], dims[1])
+    moving = x.shape[0] - 1
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("4i", x.shape[0], t.shape[0], anchors.size, 1))       # StVK
+        f.write(x.astype(np.float64).tobytes()); f.write(np.repeat(m, 3).tobytes()); f.write(t.astype(np.int32).tobytes())
+        f.write(anchors.astype(np.int32).tobytes()); f.write(struct.pack("i", moving))
+    exe = compile_cpp("scene_ranks", pkg)
+    n3 = 3 * x.shape[0]
+
+    def run(frames, iters, tag):
+        def load(path):
+            raw = np.fromfile(path, dtype=np.float64)
+            return raw[:frames * n3].reshape(frames, n3), raw[-3:]
+        one = tmp_path / (tag + "one.bin")
+        r = subprocess.run([exe, str(inp), str(one), str(frames), str(iters), "0", "1", "1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        name = "/admm_scene_ranks_%d_%d%d%s" % (os.getpid(), world, mode, tag)
+        outs = [tmp_path / ("%srank%d.bin" % (tag, k)) for k in range(world)]
+        ps = [subprocess.Popen([exe, str(inp), str(outs[k]), str(frames), str(iters), str(k), str(world), str(mode), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+              for k in range(world)]
+        res = [p.communicate(timeout=600) for p in ps]
+        assert all(p.returncode == 0 for p in ps), res
+        Xs = [load(o) for o in outs]
+        for k in range(1, world):            # replicated top / all-reduced right-hand side: every rank holds the same bits
+            assert np.array_equal(Xs[k][0], Xs[0][0]) and np.array_equal(Xs[k][1], Xs[0][1])
+        assert np.isfinite(Xs[0][0]).all()
+        return load(one), Xs[0]
+    # one ADMM iteration per frame: the partial sums meet in another order, nothing else differs -> rounding level
+    (X1, _), (Xw, _) = run(2, 1, "a")
+    assert np.abs(Xw[0] - X1[0]).max() < 1e-11
+    # ten iterations per frame, five frames: the truncated StVK prox amplifies last-bit differences of its input (the reference
+    # against itself from a 1-ulp perturbed start: 2e-6 after one frame, DESIGN.md 4.6); the released control point (frames 3, 4)
+    # follows the node on every rank
+    (X1, cp1), (Xw, cpw) = run(5, 10, "b")
+    assert np.abs(Xw - X1).max() < 2e-5
+    assert np.abs(cpw - Xw[-1][3 * moving:3 * moving + 3]).max() == 0.0
+    assert np.abs(cpw - cp1).max() < 1e-3           # (single rank: Dx of the last iteration; sharded: the node after the frame)
 
 
 @pytest.mark.gpu
