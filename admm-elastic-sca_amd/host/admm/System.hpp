@@ -130,6 +130,9 @@ public:
         }
         if (!(m_masses.size() == m_x.size() && m_x.size() >= 3)) { std::cerr << "\n**Solver Error: Problem with node data!" << std::endl; return false; }
         release();                  // (also un-pins m_x / m_v before they may be re-allocated)
+        // an UNCHANGED scene binary under a launcher: ADMM_HIP_RANKS_FROM_ENV=1 makes every process take its rank, world size
+        // and GPU from the launcher's environment (mpirun -np 8 -x ADMM_HIP_RANKS_FROM_ENV=1 ./windyflag)
+        if (shard.world == 1) { const char *auto_env = std::getenv("ADMM_HIP_RANKS_FROM_ENV"); if (auto_env && std::atoi(auto_env) != 0) { const int local = shard.from_env(); if (local >= 0) device_id = local; } }
         if (m_v.size() < m_x.size()) m_v.resize(m_x.size());
         m_v.setZero();
         if (admm_hip_create(&gpu, device_id) != ADMM_OK) { std::cerr << "\n**Solver Error: no usable HIP device " << device_id << " (the built-in forces have no CPU path)" << std::endl; gpu = nullptr; return false; }
