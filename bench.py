@@ -36,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured achievable)
+VALU_ISSUE_SLOTS_PER_S = 1024 * 2.4e9 / 4.0   # 256 CUs x 4 SIMDs at 2.4 GHz; one wave-wide VALU instruction occupies a SIMD for 4 cycles (fp64 FMA: more)
+RHS_BYTES_PER_TET, RHS_BYTES_PER_NODE = 96.0, 48.0   # rhs_gather_kernel: 4 slots x 24 B per tet + M x_bar read and b written per node
 LOCAL_BYTES_PER_TET = 472.0    # read 296 B + write 176 B per tet per ADMM iteration
 ADMM_ITERS = 20
 
@@ -128,15 +130,21 @@ def other_configs(pkg, torch, steps):
 
     def measure(s, n_el, label):
         s.initialize()
-        s.step(ADMM_ITERS); s.sync()
-        t = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(3):          # three warm-up frames (graph capture, cost-ordered launch, clocks), then the median of three timed runs
             s.step(ADMM_ITERS)
         s.sync()
-        t = (time.perf_counter() - t) / steps
+        runs = []
+        for _ in range(3):
+            t = time.perf_counter()
+            for _ in range(steps):
+                s.step(ADMM_ITERS)
+            s.sync()
+            runs.append((time.perf_counter() - t) / steps)
+        t = sorted(runs)[1]
         assert np.isfinite(s.m_x).all()
         inf = s.info()
         res[label] = {"value": ADMM_ITERS / t * n_el, "elements": int(n_el), "nodes": int(inf["n_nodes"]), "ms_per_iter": 1e3 * t / ADMM_ITERS,
+                      "ms_per_iter_runs": [round(1e3 * r / ADMM_ITERS, 5) for r in runs],
                       "solve": "explicit inverse (one kernel)" if inf["dense_solve"] else "%d levels" % inf["n_levels"]}
     try:
         s = pkg.make_bar_system(10, 10, 9); measure(s, s.n_tets, "configs[1] NH bar 10x10x9 = 5400 tets"); del s
@@ -391,23 +399,59 @@ def main():
     # WRITE_SIZE is exact (8.57 / 12.86 MB).  So traffic = 2 x FETCH_SIZE + WRITE_SIZE.
     traffic = None
     valu = None
-    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r02/pmc_1M.json"))
+    sweeps = None
+    bound = "hbm"
+    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r03/pmc_1M.json"))
+    if not os.path.exists(os.path.join(ROOT, pmc_file)):
+        pmc_file = os.path.join("profiles", "r02/pmc_1M.json")
     try:
-        if (nx, ny, nz) == (32, 32, 163) and world == 1 and dom.startswith("project_tet_kernel"):
-            pm = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]["admm_dev::project_tet_kernel<0, 5>"]
-            traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
-            # the kernel is fp64-VALU-issue bound, not HBM bound: share of a wave's life spent issuing VALU work, x 2 resident waves per SIMD
-            busy = pm["SQ_ACTIVE_INST_VALU"]["per_launch"] / pm["SQ_WAVE_CYCLES"]["per_launch"]
-            valu = {"valu_insts_per_launch": pm["SQ_INSTS_VALU"]["per_launch"], "fma_f64_insts": pm["SQ_INSTS_VALU_FMA_F64"]["per_launch"],
-                    "valu_busy_per_wave": busy, "waves_per_simd": 2, "simd_valu_issue_frac": min(1.0, 2 * busy),
-                    "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"])}
-    except Exception:
+        if (nx, ny, nz) == (32, 32, 163) and world == 1:
+            kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
+            tet_key = [k for k in kern if "project_tet_kernel<0, 5" in k][0]
+            iters_pmc = float(kern[tet_key]["FETCH_SIZE"]["launches"])       # the PMC passes ran this many ADMM iterations (one tet launch each)
+
+            def sweep_traffic(match):      # bytes per ADMM iteration over every kernel of a sweep: 2 x FETCH_SIZE + WRITE_SIZE (KiB per launch x launches)
+                tot = 0.0
+                for k, v in kern.items():
+                    if any(m in k for m in match):
+                        tot += (2.0 * v["FETCH_SIZE"]["per_launch"] * v["FETCH_SIZE"]["launches"] + v["WRITE_SIZE"]["per_launch"] * v["WRITE_SIZE"]["launches"]) * 1024.0
+                return tot / iters_pmc
+            fwd_alg = info["nnz_L"] * 8.0 + info["n_nodes"] * 24.0 * 3
+            fwd_tr, bwd_tr = sweep_traffic(("solve_fwd_", "root_gather_kernel", "root_product_kernel")), sweep_traffic(("solve_bwd_kernel",))
+            sweeps = {"forward": {"algorithmic_bytes": fwd_alg, "traffic": fwd_tr, "traffic_over_algorithmic": fwd_tr / fwd_alg, "ms": fwd_s * 1e3, "GB/s": fwd_alg / fwd_s / 1e9 if fwd_s > 0 else 0.0},
+                      "backward": {"algorithmic_bytes": fwd_alg, "traffic": bwd_tr, "traffic_over_algorithmic": bwd_tr / fwd_alg, "ms": bwd_s * 1e3, "GB/s": fwd_alg / bwd_s / 1e9 if bwd_s > 0 else 0.0}}
+            if dom.startswith("project_tet_kernel"):
+                pm = kern[tet_key]
+                traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
+                # the kernel is fp64-VALU bound, not HBM bound.  valu_frac: the launch's wave-wide VALU instructions x the 4 cycles each
+                # occupies a SIMD, over the chip's issue capacity for the launch's duration (a LOWER bound on VALU occupancy: fp64
+                # multiplies, FMAs, divisions' and square roots' helper sequences take more than 4 cycles)
+                busy = pm["SQ_ACTIVE_INST_VALU"]["per_launch"] / pm["SQ_WAVE_CYCLES"]["per_launch"]
+                valu = {"valu_insts_per_launch": pm["SQ_INSTS_VALU"]["per_launch"], "fma_f64_insts": pm["SQ_INSTS_VALU_FMA_F64"]["per_launch"],
+                        "valu_busy_per_wave": busy, "waves_per_simd": 2, "simd_valu_issue_frac": min(1.0, 2 * busy),
+                        "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"]),
+                        "issue_floor_ms": 1e3 * pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S,
+                        "valu_frac": (pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S) / sec if sec > 0 else 0.0}
+                bound = "valu"
+    except Exception as e:  # noqa: BLE001 -- counters are side information
         traffic = None
-    roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        print("bench: PMC summary %s unusable: %r" % (pmc_file, e), file=sys.stderr)
+    # the whole ADMM iteration against the HBM roof: algorithmic bytes of every kernel of one iteration over the iteration's time
+    it_s = phase["total_ms"] * 1e-3 / iters_total
+    it_bytes = (LOCAL_BYTES_PER_TET + RHS_BYTES_PER_TET) * (n_tets / world) + RHS_BYTES_PER_NODE * info["n_nodes"] + 2.0 * panel_bytes
+    iteration = None
+    if a.config == "bar" and not (world > 1 and a.shard == "subtree"):
+        iteration = {"bytes": it_bytes, "ms": it_s * 1e3, "GB/s": it_bytes / it_s / 1e9 if it_s > 0 else 0.0, "frac": (it_bytes / it_s / 1e9 / HBM_PEAK_GBS) if it_s > 0 else 0.0,
+                     "what": "tet kernel 472 B/tet + RHS gather 96 B/tet + 48 B/node + the factor panels and vectors once per sweep, over the mean ADMM iteration (HIP events, total_ms)"}
+    roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
-            # achieved / avg_launch_ms are THIS run's HIP events; traffic / valu are PMC counters and cannot be collected in the same
-            # process: they come from the committed rocprofv3 --pmc passes of the same command (tools/pmc_collect.sh)
-            "traffic_source": (pmc_file if traffic is not None else None),
+            "valu_frac": (valu or {}).get("valu_frac"),
+            "note": ("bound = valu: the dominant kernel is limited by fp64 VALU issue / dependency latency; achieved / peak / frac keep the HBM yardstick "
+                     "the contract asks for, valu_frac is the fraction of the roof that actually binds" if bound == "valu" else None),
+            # achieved / avg_launch_ms are THIS run's HIP events; traffic / valu / sweeps.traffic are PMC counters and cannot be collected in
+            # the same process: they come from the committed rocprofv3 --pmc passes of the same command (tools/pmc_collect.sh)
+            "traffic_source": (pmc_file if (traffic is not None or sweeps is not None) else None),
+            "iteration": iteration, "sweeps": sweeps,
             "phases_ms_per_iter": {k: v / iters_total for k, v in phase.items()},
             "all": {k: {"GB/s": (v[0] / v[1] / 1e9 if v[1] > 0 else 0.0), "ms": v[1] * 1e3} for k, v in cands.items()}}
 
@@ -449,19 +493,26 @@ def main():
         hx = s.m_x.copy(); hv = s.m_v.copy()
         s.pin_host(hx); s.pin_host(hv)
         s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
-        tc = time.perf_counter()
-        for _ in range(a.steps):
-            s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
-        tc = (time.perf_counter() - tc) / a.steps
-        tr = time.perf_counter()
-        for _ in range(a.steps):
-            s.step(ADMM_ITERS)
-        s.sync()
-        tr = (time.perf_counter() - tr) / a.steps
+        nf = max(a.steps, 12)        # 12+ frames each, alternated in blocks of 4 so that clock drift hits both alike
+        tc = tr = 0.0
+        for _ in range(nf // 4):
+            t = time.perf_counter()
+            for _ in range(4):
+                s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
+            tc += time.perf_counter() - t
+            t = time.perf_counter()
+            for _ in range(4):
+                s.step(ADMM_ITERS)
+            s.sync()
+            tr += time.perf_counter() - t
+        nf = 4 * (nf // 4)
+        tc /= nf; tr /= nf
         s.pin_host(hx, False); s.pin_host(hv, False)
+        pcie_floor = 4.0 * 8.0 * 3 * info["n_nodes"] / 64e9         # four vectors over PCIe 5 x16 (64 GB/s each way)
         out["class_api"] = {"ms_per_step": 1e3 * tc, "resident_ms_per_step": 1e3 * tr, "value": ADMM_ITERS / tc * n_tets, "overhead_frac": tc / tr - 1.0,
+                            "pcie_floor_frac": pcie_floor / tr, "frames": nf,
                             "what": "admm_hip_upload_state(m_x, m_v) + admm_hip_step + admm_hip_download_state(m_x, m_v) per frame, event-free, "
-                                    "vs. the same %d frames with the state resident" % a.steps}
+                                    "vs. the same %d frames with the state resident (blocks of 4 frames alternated)" % nf}
         out["other_configs"] = other_configs(pkg, torch, a.steps)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 side figure
