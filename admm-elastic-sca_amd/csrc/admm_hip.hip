@@ -38,6 +38,7 @@ struct Batch {
     std::vector<double> targets;   // anchors [n_total][3]
     bool moving = false;
     std::vector<int32_t> active;   // anchors [n_total]
+    std::vector<int> grp_ptr, grp_blk;   // pipeline groups: element range / first 64-element block of every group in the (group-major) local order, [G + 1]
     double *h_tg = nullptr; int32_t *h_ac = nullptr; hipEvent_t upd_ev = nullptr;   // anchors: pinned staging of this rank's targets / flags + "last update has left it"
     // finalize
     std::vector<double> weight, rest, measure;  // [n_total], [n_total][12], [n_total]
@@ -141,6 +142,17 @@ struct admm_hip_ctx {
     bool fuse_anchor_tail = true;                 // an anchor batch right behind a tet batch goes out in the tet launch (ADMM_HIP_FUSE_ANCHORS=0: own launch)
     bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
     int groups = 1;
+    // Pipelined groups on ONE GPU (ADMM_HIP_PIPE=G, world 1): the elements and the elimination subtrees below a small top are cut
+    // into G independent groups (same partition as `groups`); group g's chain  bwd_g(k-1) -> local step_g(k) -> rhs_g(k) -> fwd_g(k)
+    // runs on its own stream and only the top of the tree joins them, so one group's latency-bound sweeps run under another
+    // group's VALU-bound local step.  The element arrays of every batch are group-major (Batch::grp_ptr); without the pipeline
+    // (timed iterations, residual tracking) the same layout is launched group after group on one stream: bitwise the same result.
+    int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
+    std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
+    std::vector<std::vector<std::pair<int, int> > > pipe_nodes;      // [G + 1] node ranges (factor order) of every group's subtrees; last = the top
+    std::vector<hipStream_t> pipe_local_streams;                      // optional CU-masked streams for the groups' local step (pipe_cu_mask)
+    std::vector<hipEvent_t> pipe_ev_fwd, pipe_ev_tet, pipe_ev_sw; hipEvent_t pipe_ev_top = nullptr;
+    hipGraphExec_t pipe_exec[3] = {nullptr, nullptr, nullptr}; hipGraph_t pipe_graph_h[3] = {nullptr, nullptr, nullptr};   // first / middle iteration, closing backward sweeps
     std::vector<int> grp_owner;               // per supernode: group, -1 = top
     std::vector<std::vector<LevelDev> > levels_side;
     std::vector<LevelDev> levels_gtop;
@@ -264,6 +276,10 @@ template <class T> int upload(admm_hip_ctx *ctx, T **p, const std::vector<T> &h)
 void free_device(admm_hip_ctx *ctx) {
     if (ctx->iter_exec) { (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr; }
     if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
+    for (int q = 0; q < 3; ++q) {
+        if (ctx->pipe_exec[q]) { (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; }
+        if (ctx->pipe_graph_h[q]) { (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }
+    }
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
     for (Batch &b : ctx->batches) {
@@ -751,6 +767,7 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     const int ns = (int)F.sn.size(), world = ctx->world;
     ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
     ctx->grp_owner.clear();
+    if (ctx->pipe > 1 && (world > 1 || ctx->dense)) { ctx->pipe = 0; ctx->groups = 1; }      // the pipeline is a one-GPU mode of the panel sweeps
     if (!(ctx->shard_mode == 1 && world > 1) && ctx->groups > 1 && !ctx->dense) {      // concurrent groups on this GPU
         std::vector<double> load; int nt = 0; size_t nsub = 0;
         subtree_owners(F, ctx->groups, ctx->grp_owner, load, nt, nsub);
@@ -758,6 +775,20 @@ void partition_subtrees(admm_hip_ctx *ctx) {
             fprintf(stderr, "admm_hip: %d concurrent subtree groups: %d top supernodes, %zu subtrees, load per group (1e6 entries):", ctx->groups, nt, nsub);
             for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
             fprintf(stderr, "\n");
+        }
+        ctx->pipe_node_group.clear(); ctx->pipe_nodes.clear();
+        if (ctx->pipe > 1 && world == 1) {      // nodes of every group (supernodes are contiguous runs of the factor order; neighbours merge)
+            ctx->pipe_node_group.assign(F.n, -1);
+            ctx->pipe_nodes.assign(ctx->pipe + 1, {});
+            std::vector<int> by_first(ns);
+            std::iota(by_first.begin(), by_first.end(), 0);
+            std::sort(by_first.begin(), by_first.end(), [&](int a, int b) { return F.sn[a].first < F.sn[b].first; });
+            for (int s : by_first) {
+                const int g = ctx->grp_owner[s], a = F.sn[s].first, e = a + F.sn[s].ncols;
+                for (int j = a; j < e; ++j) ctx->pipe_node_group[j] = g;
+                std::vector<std::pair<int, int> > &R = ctx->pipe_nodes[g < 0 ? ctx->pipe : g];
+                if (!R.empty() && R.back().second == a) R.back().second = e; else R.push_back({a, e});
+            }
         }
     }
     if (ctx->shard_mode != 1 || world <= 1) return;
@@ -788,6 +819,27 @@ void assign_elements(admm_hip_ctx *ctx) {
         } else {   // contiguous ranges (reference order preserved inside a rank)
             const int first = (int)((int64_t)b.n_total * ctx->rank / ctx->world), end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
             for (int e = first; e < end; ++e) b.local.push_back(e);
+        }
+        b.grp_ptr.clear(); b.grp_blk.clear();
+        if (ctx->pipe > 1 && ctx->world == 1 && !ctx->grp_owner.empty()) {
+            // group-major: an element belongs to the group of its first node below the top (all its nodes below the top lie in ONE
+            // subtree); elements entirely inside the top are dealt round-robin.  Reference order is kept inside a group.
+            const int G = ctx->pipe;
+            std::vector<int> grp(b.local.size());
+            for (size_t el = 0; el < b.local.size(); ++el) {
+                int g = -1;
+                const int32_t *nd; const int nn = b.elem_nodes(b.local[el], &nd);
+                for (int c = 0; c < nn && g < 0; ++c) g = ctx->pipe_node_group[F.iperm[nd[c]]];
+                grp[el] = g < 0 ? (int)(b.local[el] % G) : g;
+            }
+            std::vector<int32_t> sorted; sorted.reserve(b.local.size());
+            b.grp_ptr.assign(G + 1, 0); b.grp_blk.assign(G + 1, 0);
+            for (int g = 0; g < G; ++g) {
+                for (size_t el = 0; el < b.local.size(); ++el) if (grp[el] == g) sorted.push_back(b.local[el]);
+                b.grp_ptr[g + 1] = (int)sorted.size();
+                b.grp_blk[g + 1] = b.grp_blk[g] + (b.grp_ptr[g + 1] - b.grp_ptr[g] + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK;
+            }
+            b.local.swap(sorted);
         }
         b.n_local = (int)b.local.size();
         nloc += b.n_local;
@@ -1117,9 +1169,10 @@ int upload_all(admm_hip_ctx *ctx) {
         b.d_order = nullptr; b.d_cost = nullptr; b.n_blocks_ordered = 0;
         {
             // more blocks than the chip holds at once (2 waves x 4 SIMDs x 256 CUs): the launch order matters
-            const int nblk = (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK;
+            const int nblk = b.grp_blk.empty() ? (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK : b.grp_blk.back();
             if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && ctx->tet_order && nblk > ctx->tet_order_min_blocks) {
                 std::vector<int> ident(nblk); std::iota(ident.begin(), ident.end(), 0);
+                for (size_t g = 0; g + 1 < b.grp_blk.size(); ++g) std::iota(ident.begin() + b.grp_blk[g], ident.begin() + b.grp_blk[g + 1], 0);      // per group: ids relative to the group's first block
                 TRY(upload(ctx, &b.d_order, ident));
                 TRY(dalloc(ctx, &b.d_cost, (size_t)nblk));
                 HIPCHK(hipMemset(b.d_cost, 0, sizeof(unsigned int) * (size_t)nblk));
@@ -1182,7 +1235,7 @@ int upload_all(admm_hip_ctx *ctx) {
 
 BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     BatchDev d{};
-    d.n = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
+    d.n = b.n_local; d.e0 = 0; d.e1 = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
     d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
     d.fslot = ctx->d_fslot; d.dst = b.d_dst; d.targets = b.d_targets; d.active = b.d_active;
     d.dx_override = b.d_dx_override;
@@ -1210,21 +1263,32 @@ void tet_trace_next(hipStream_t st) {
     hipMemcpyToSymbolAsync(HIP_SYMBOL(admm_dev::g_tet_trace), &p, sizeof(p), 0, hipMemcpyHostToDevice, st);
 }
 #endif
-int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
+// `group` >= 0 (pipeline groups, Batch::grp_ptr): only that group's elements of every batch, on stream `st`; group < 0 with a
+// group-major layout: group after group on one stream (the serial launch of the same layout)
+int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStream_t st = nullptr) {
     using namespace admm_dev;
+    if (!st) st = ctx->stream;
     bool skip_next = false;
     for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
         const Batch &b = ctx->batches[bi];
         if (only_batch >= 0 && (int)bi != only_batch) continue;
         if (skip_next) { skip_next = false; continue; }                  // (an anchor batch that went out with the tets before it)
         if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;     // user-defined forces: generic_begin / generic_finish
-        const BatchDev d = batch_dev(ctx, b);
-        dim3 grid((b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
+        const bool grouped = !b.grp_ptr.empty();
+        const int g_first = grouped ? (group >= 0 ? group : 0) : 0, g_last = grouped ? (group >= 0 ? group + 1 : (int)b.grp_ptr.size() - 1) : 1;
+      for (int g = g_first; g < g_last; ++g) {
+        BatchDev d = batch_dev(ctx, b);
+        if (grouped) {
+            d.e0 = b.grp_ptr[g]; d.e1 = b.grp_ptr[g + 1];
+            if (d.e1 == d.e0) continue;
+            if (d.order) { d.order += b.grp_blk[g]; d.cost += b.grp_blk[g]; }
+        }
+        dim3 grid((d.e1 - d.e0 + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
         const double *x = ctx->d_xcur;
         // an anchor batch right behind a tet batch rides along in the tet launch (project_tet_kernel's tail)
         BatchDev tail{}; const int tail_block0 = (int)grid.x;
         const bool is_tet = b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK || b.kind == ADMM_KIND_TET_LINEAR || b.kind == ADMM_KIND_TET_VOLUME;
-        if (is_tet && only_batch < 0 && ctx->fuse_anchor_tail && bi + 1 < ctx->batches.size() && ctx->batches[bi + 1].kind == ADMM_KIND_ANCHOR && ctx->batches[bi + 1].n_local > 0) {
+        if (is_tet && !grouped && only_batch < 0 && ctx->fuse_anchor_tail && bi + 1 < ctx->batches.size() && ctx->batches[bi + 1].kind == ADMM_KIND_ANCHOR && ctx->batches[bi + 1].n_local > 0) {
             tail = batch_dev(ctx, ctx->batches[bi + 1]);
             grid.x += (ctx->batches[bi + 1].n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
             skip_next = true;
@@ -1232,26 +1296,27 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1) {
         switch (b.kind) {
         case ADMM_KIND_TET_NH:
 #ifdef ADMM_TET_PROFILE
-            tet_trace_next(ctx->stream);
+            tet_trace_next(st);
 #endif
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
-            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, st, d, x, tail, tail_block0);
+            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, st, d, x, tail, tail_block0);
             break;
         case ADMM_KIND_TET_STVK:
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
-            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, ctx->stream, d, x, tail, tail_block0);
+            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, st, d, x, tail, tail_block0);
+            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, st, d, x, tail, tail_block0);
             break;
-        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, ctx->stream, d, x, tail, tail_block0); break;
-        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, ctx->stream, d, x, tail, tail_block0); break;
-        case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel<0>, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_TRI_AREA: hipLaunchKernelGGL(project_tri_kernel<1>, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_TRI_FUNG: hipLaunchKernelGGL(project_tri_kernel<2>, grid, block, 0, ctx->stream, d, x); break;
-        case ADMM_KIND_COLLISION: hipLaunchKernelGGL(project_collision_kernel, grid, block, 0, ctx->stream, d, x, (const ShapeTable *)ctx->d_shapes); break;
+        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, st, d, x, tail, tail_block0); break;
+        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, st, d, x, tail, tail_block0); break;
+        case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel<0>, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_TRI_AREA: hipLaunchKernelGGL(project_tri_kernel<1>, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_TRI_FUNG: hipLaunchKernelGGL(project_tri_kernel<2>, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_COLLISION: hipLaunchKernelGGL(project_collision_kernel, grid, block, 0, st, d, x, (const ShapeTable *)ctx->d_shapes); break;
         default: return fail(ctx, ADMM_ERR_UNSUPPORTED, "no kernel for kind %d", b.kind);
         }
+      }
     }
     HIPCHK(hipGetLastError());
     return ADMM_OK;
@@ -1284,16 +1349,24 @@ int generic_finish(admm_hip_ctx *ctx) {
     return ADMM_OK;
 }
 
-int launch_rhs(admm_hip_ctx *ctx) {
-    const int n3 = 3 * ctx->n_nodes;
-    hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride,
-                       ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, (const unsigned char *)ctx->d_base_mask, ctx->d_y);
+// group >= 0: only the nodes of that pipeline group's subtrees (group == ctx->pipe: the top), on stream `st`
+int launch_rhs(admm_hip_ctx *ctx, int group = -1, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
+    auto range = [&](int a, int e) {
+        const int n3 = 3 * (e - a);
+        if (n3 > 0) hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, a, e, ctx->d_inc_ptr, ctx->slot_stride,
+                                       ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, (const unsigned char *)ctx->d_base_mask, ctx->d_y);
+    };
+    if (group < 0) range(0, ctx->n_nodes);
+    else for (const std::pair<int, int> &r : ctx->pipe_nodes[group]) range(r.first, r.second);
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
 
 // both triangular sweeps: d_y (rhs, destroyed) -> d_xcur
-int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hipEvent_t ex1 = nullptr) {
+// part (pipeline groups): 0 = everything (default); otherwise ONE piece on stream `pst`: 1 = forward sweep of group `pg`'s subtrees,
+// 2 = backward sweep of group pg, 3 = the top (forward, roots, backward)
+int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hipEvent_t ex1 = nullptr, int part = 0, int pg = 0, hipStream_t pst = nullptr) {
     using namespace admm_dev;
     if (ctx->dense) {   // small system: one kernel, x = A_s^-1 b
         if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
@@ -1337,6 +1410,27 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
         }
     };
     const int n_side = (int)ctx->levels_side.size();
+    if (part) {
+        const std::vector<LevelDev> &mine = pg == 0 ? ctx->levels : ctx->levels_side[pg - 1];
+        if (part == 1) forward(mine, pst);
+        else if (part == 2) backward(mine, pst);
+        else { forward(ctx->levels_gtop, pst); backward(ctx->levels_gtop, pst); }
+        HIPCHK(hipGetLastError());
+        if (bad_pair) return fail(ctx, ADMM_ERR_STATE, "backward sweep: no kernel for a level's (columns per wave, waves per block) pair");
+        return ADMM_OK;
+    }
+    if (ctx->pipe > 1) {      // pipeline layout launched serially: group after group on the context's stream, then the top
+        forward(ctx->levels, ctx->stream);
+        for (int g = 0; g < n_side; ++g) forward(ctx->levels_side[g], ctx->stream);
+        forward(ctx->levels_gtop, ctx->stream);
+        if (mid) HIPCHK(hipEventRecord(mid, ctx->stream));
+        backward(ctx->levels_gtop, ctx->stream);
+        backward(ctx->levels, ctx->stream);
+        for (int g = 0; g < n_side; ++g) backward(ctx->levels_side[g], ctx->stream);
+        HIPCHK(hipGetLastError());
+        if (bad_pair) return fail(ctx, ADMM_ERR_STATE, "backward sweep: no kernel for a level's (columns per wave, waves per block) pair");
+        return ADMM_OK;
+    }
     // concurrent groups: the side streams start when the right-hand side is there and hand back before the top
     auto fork = [&]() -> int {
         if (!n_side) return ADMM_OK;
@@ -1377,6 +1471,87 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
     TRY(join());
     HIPCHK(hipGetLastError());
     if (bad_pair) return fail(ctx, ADMM_ERR_STATE, "backward sweep: no kernel for a level's (columns per wave, waves per block) pair");
+    return ADMM_OK;
+}
+
+// ---- pipelined groups (ADMM_HIP_PIPE=G): one frame's ADMM loop ------------------------------------------------------------
+// Streams: group 0 and the top on the context's stream M, group g > 0 on side stream g - 1.  Per ADMM iteration k
+//   S_g : wait top(k-1) | bwd_g(k-1) | local step_g(k) [after local step_{g-1}(k) when chained] | rhs_g(k) | fwd_g(k) | done_g
+//   M   : ... group 0's chain ... | wait done_g (g > 0) | rhs_top(k) | fwd_top, roots, bwd_top (k) | top(k)
+// and after the last iteration every group's backward sweep.  Same kernels on the same data as the serial launch of this layout
+// (launch_local / launch_rhs / launch_solve group after group): bitwise the same x.  With pipe_graph the three shapes of an
+// iteration (first: no backward sweeps yet; middle; closing sweeps) are captured once as multi-stream graphs: one graph launch
+// per iteration instead of ~25 launches + event operations per group.
+static int pipe_piece(admm_hip_ctx *ctx, int shape) {
+    const int G = ctx->pipe;
+    auto S = [&](int g) { return g == 0 ? ctx->stream : ctx->side_streams[g - 1]; };
+    auto L = [&](int g) { return ctx->pipe_local_streams.empty() ? S(g) : ctx->pipe_local_streams[g]; };
+    HIPCHK(hipEventRecord(ctx->pipe_ev_top, ctx->stream));                       // what came before on M: prologue / the previous top
+    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(S(g), ctx->pipe_ev_top, 0));
+    for (int g = 0; g < G; ++g) {
+        if (shape >= 1) TRY(launch_solve(ctx, nullptr, nullptr, nullptr, 2, g, S(g)));      // bwd_g of the previous iteration
+        if (shape == 2) continue;
+        hipStream_t ls = L(g);
+        if (ls != S(g)) { HIPCHK(hipEventRecord(ctx->pipe_ev_sw[g], S(g))); HIPCHK(hipStreamWaitEvent(ls, ctx->pipe_ev_sw[g], 0)); }
+        if (ctx->pipe_chain && g > 0) HIPCHK(hipStreamWaitEvent(ls, ctx->pipe_ev_tet[g - 1], 0));
+        TRY(launch_local(ctx, -1, g, ls));
+        if (ctx->pipe_chain || ls != S(g)) HIPCHK(hipEventRecord(ctx->pipe_ev_tet[g], ls));
+        if (ls != S(g)) HIPCHK(hipStreamWaitEvent(S(g), ctx->pipe_ev_tet[g], 0));
+        TRY(launch_rhs(ctx, g, S(g)));
+        TRY(launch_solve(ctx, nullptr, nullptr, nullptr, 1, g, S(g)));
+    }
+    for (int g = 1; g < G; ++g) { HIPCHK(hipEventRecord(ctx->pipe_ev_fwd[g], S(g))); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->pipe_ev_fwd[g], 0)); }
+    if (shape == 2) return ADMM_OK;
+    TRY(launch_rhs(ctx, G, ctx->stream));
+    TRY(launch_solve(ctx, nullptr, nullptr, nullptr, 3, 0, ctx->stream));
+    return ADMM_OK;
+}
+int pipe_frame(admm_hip_ctx *ctx, int admm_iters) {
+    const int G = ctx->pipe;
+    if ((int)ctx->pipe_ev_fwd.size() < G) {
+        for (int g = 0; g < G; ++g) {
+            hipEvent_t a, b, c;
+            HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c, hipEventDisableTiming));
+            ctx->pipe_ev_fwd.push_back(a); ctx->pipe_ev_tet.push_back(b); ctx->pipe_ev_sw.push_back(c);
+        }
+        HIPCHK(hipEventCreateWithFlags(&ctx->pipe_ev_top, hipEventDisableTiming));
+        if (ctx->pipe_cu_mask > 0) {      // the local step on streams that leave `pipe_cu_mask` CUs of every XCD to the sweeps
+            // CU mask bit i = CU i; CUs are numbered XCD-interleaved on this part (CU i -> XCD i mod 8): drop the highest-numbered ones
+            const int ncu = 256, drop = std::min(ncu - 8, 8 * ctx->pipe_cu_mask);
+            std::vector<uint32_t> mask(ncu / 32, 0xffffffffu);
+            for (int i = ncu - drop; i < ncu; ++i) mask[i / 32] &= ~(1u << (i % 32));
+            for (int g = 0; g < G; ++g) {
+                hipStream_t st = nullptr;
+                if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); ctx->pipe_local_streams.clear(); fprintf(stderr, "admm_hip: CU-masked streams unavailable\n"); break; }
+                ctx->pipe_local_streams.push_back(st);
+            }
+        }
+    }
+    // (a CU-masked stream inside a stream capture crashes the HIP runtime of this image: masked runs launch eagerly)
+    const bool want_graph = ctx->pipe_graph && ctx->graph_enabled && ctx->pipe_local_streams.empty();
+    if (want_graph && !ctx->pipe_exec[0]) {
+        for (int shape = 0; shape < 3; ++shape) {
+            const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+            const int rc = be == hipSuccess ? pipe_piece(ctx, shape) : ADMM_ERR_HIP;
+            hipGraph_t g = nullptr;
+            const hipError_t ce = be == hipSuccess ? hipStreamEndCapture(ctx->stream, &g) : be;
+            if (rc || ce != hipSuccess || !g || hipGraphInstantiate(&ctx->pipe_exec[shape], g, nullptr, nullptr, 0) != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                for (int q = 0; q < 3; ++q) { if (ctx->pipe_exec[q]) (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; if (ctx->pipe_graph_h[q]) (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }
+                ctx->pipe_graph = false;
+                fprintf(stderr, "admm_hip: pipeline graph capture unavailable (shape %d), launching eagerly\n", shape);
+                break;
+            }
+            ctx->pipe_graph_h[shape] = g;
+        }
+    }
+    const bool graph = want_graph && ctx->pipe_exec[0] && ctx->pipe_exec[1] && ctx->pipe_exec[2];
+    for (int it = 0; it < admm_iters; ++it) {
+        const int shape = it == 0 ? 0 : 1;
+        if (graph) HIPCHK(hipGraphLaunch(ctx->pipe_exec[shape], ctx->stream)); else TRY(pipe_piece(ctx, shape));
+    }
+    if (graph) HIPCHK(hipGraphLaunch(ctx->pipe_exec[2], ctx->stream)); else TRY(pipe_piece(ctx, 2));
     return ADMM_OK;
 }
 
@@ -1478,7 +1653,7 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
         first = false;
     }
     if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
+    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, 0, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
     if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
         TRY(do_allreduce(ctx, ctx->d_res_s, (int64_t)n3));
         TRY(do_allreduce(ctx, r2, 1));
@@ -1517,7 +1692,18 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
             delete ctx;
             return ADMM_ERR_HIP;
         }
-        if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return ADMM_ERR_HIP; }
+        if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return ADMM_ERR_HIP; }
+        // probe knob (tools/probe/cu_mask_probe.py): the context's own stream restricted to a CU set, ADMM_HIP_STREAM_CUMASK = 64 hex digits
+        // (256 bits, most significant first) -- how the phases scale with the CUs they may use
+        const char *cm = getenv("ADMM_HIP_STREAM_CUMASK");
+        bool made = false;
+        if (cm && std::strlen(cm) == 64) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) { char buf[9]; std::memcpy(buf, cm + 8 * (7 - w), 8); buf[8] = 0; mask[w] = (uint32_t)std::strtoul(buf, nullptr, 16); }
+            made = hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask) == hipSuccess;
+            if (!made) { (void)hipGetLastError(); fprintf(stderr, "admm_hip: CU-masked stream unavailable\n"); }
+        }
+        if (!made && hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return ADMM_ERR_HIP; }
         ctx->own_stream = true;
     }
     ctx->info.device_id = device_id; ctx->info.world = 1;
@@ -1539,6 +1725,10 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_CW2_MIN")) ctx->bwd_cw2_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_CW2_MAX")) ctx->bwd_cw2_max_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
+    if (const char *g = getenv("ADMM_HIP_PIPE")) { const int v = atoi(g); if (v >= 2 && v <= 8) { ctx->pipe = v; ctx->groups = v; } }
+    if (const char *g = getenv("ADMM_HIP_PIPE_CHAIN")) ctx->pipe_chain = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_PIPE_GRAPH")) ctx->pipe_graph = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_PIPE_CUMASK")) ctx->pipe_cu_mask = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_NW_MIN_COLS")) ctx->bwd_nw_min_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW16_TILES")) ctx->fwd_nw16_max_tiles = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FWD_NW4")) ctx->fwd_nw4_kmax = atoi(g);
@@ -1560,6 +1750,11 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->pipe_ev_sw) (void)hipEventDestroy(e);
+        if (ctx->pipe_ev_top) (void)hipEventDestroy(ctx->pipe_ev_top);
         for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         for (hipEvent_t e : ctx->ev_join) (void)hipEventDestroy(e);
@@ -1785,6 +1980,11 @@ static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, v
     if (!ctx->host_allreduce) return 1;
     if ((size_t)count > ctx->h_comm_cap) {
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->pipe_ev_sw) (void)hipEventDestroy(e);
+        if (ctx->pipe_ev_top) (void)hipEventDestroy(ctx->pipe_ev_top);
         ctx->h_comm = nullptr; ctx->h_comm_cap = 0;
         if (hipHostMalloc((void **)&ctx->h_comm, sizeof(double) * (size_t)count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
         ctx->h_comm_cap = (size_t)count;
@@ -1942,7 +2142,11 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_timed = 0; ctx->ev_pending = ctx->timing;
     TRY(mark(ctx));
     if (ctx->frames++ > 0)      // the blocks of the large tet batches by what they cost in the frame before
-        for (const Batch &b : ctx->batches) if (b.n_blocks_ordered) hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.n_blocks_ordered, b.d_cost, b.d_order);
+        for (const Batch &b : ctx->batches) if (b.n_blocks_ordered) {
+            if (b.grp_blk.empty()) hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.n_blocks_ordered, b.d_cost, b.d_order);
+            else for (size_t g = 0; g + 1 < b.grp_blk.size(); ++g) if (b.grp_blk[g + 1] > b.grp_blk[g])
+                hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, ctx->stream, b.grp_blk[g + 1] - b.grp_blk[g], b.d_cost + b.grp_blk[g], b.d_order + b.grp_blk[g]);
+        }
     if (ctx->explicit_simple) {
         hipLaunchKernelGGL(prologue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->grav, ctx->d_x, ctx->d_v, ctx->d_m3, ctx->d_mxbar, ctx->d_xcur);
     } else {
@@ -1986,6 +2190,16 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     ctx->res_n = 0;
     int iters_done = 0;
     const int stride = std::max(1, ctx->timing_stride);
+    // pipelined groups: the whole frame's ADMM loop on G streams (no timing events, residuals or user forces inside)
+    if (ctx->pipe > 1 && !ctx->timing && !track && !ctx->n_gen_rows && admm_iters > 0) {
+        TRY(pipe_frame(ctx, admm_iters));
+        ctx->ev_iters = admm_iters;
+        TRY(mark(ctx));
+        hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
+        HIPCHK(hipGetLastError());
+        TRY(mark(ctx));
+        return ADMM_OK;
+    }
     for (int it = 0; it < admm_iters; ++it) {
         // the sampled iterations rotate from frame to frame: an iteration's cost depends on its position in the frame (the first
         // ones after the prologue do the most line-search work), a fixed phase would bias the average

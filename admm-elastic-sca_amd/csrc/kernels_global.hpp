@@ -128,11 +128,12 @@ __global__ void permute_out_kernel(int n_nodes, const int *__restrict__ perm, co
 #ifndef ADMM_RHS_UNROLL
 #define ADMM_RHS_UNROLL 1
 #endif
-__global__ void rhs_gather_kernel(int n_nodes, const int64_t *__restrict__ inc_ptr, int slot_stride,
+// The launch covers the nodes [node0, node1): all of them, or one pipeline group's node ranges (admm_hip.hip pipe_*).
+__global__ void rhs_gather_kernel(int node0, int node1, const int64_t *__restrict__ inc_ptr, int slot_stride,
                                   const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base,
                                   const unsigned char *__restrict__ base_mask, double *__restrict__ y) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n_nodes) return;
+    const int i = 3 * node0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * node1) return;
     const int node = i / 3, c = i - 3 * node;
     double acc = 0.0;
     const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];

@@ -45,7 +45,8 @@ constexpr int LOCAL_BLOCK = ADMM_LOCAL_BLOCK;
 struct ShapeTable { int n; int type[ADMM_MAX_SHAPES]; double par[ADMM_MAX_SHAPES][4]; };
 
 struct BatchDev {
-    int n;                 // local elements
+    int n;                 // local elements (= the SoA arrays' stride)
+    int e0, e1;            // the launch covers elements [e0, e1): the whole batch, or one pipeline group's range (admm_hip.hip pipe_*)
     const int *idx;        // [n][4]
     const double *rest;    // SoA [12][n]
     const double *par;     // SoA [P][n]
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(1024) void order_by_cost_kernel(int n_blocks, unsig
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const double *__restrict__ x, int e) {
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     const int id = b.idx[e];
     const double s = b.w2h2[e];
     const bool act = b.active[e] != 0;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const dou
     }
 }
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
-    project_anchor_elem(b, x, blockIdx.x * LOCAL_BLOCK + threadIdx.x);
+    project_anchor_elem(b, x, b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x);
 }
 
 template <int KIND, int M>
@@ -185,15 +186,15 @@ __global__ __launch_bounds__(LOCAL_BLOCK)
 void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail, int tail_block0) {
     // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
     // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
-    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem(tail, x, ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x); return; }
+    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem(tail, x, tail.e0 + ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x); return; }
     // Launch order by cost: a block's time depends on its slowest line search (2-4 or 20 evaluations, spatially clustered); in mesh
     // order the expensive blocks of the 1M-tet bar come last and the launch ends with a 50 us tail of a few hundred waves.  The blocks
     // that took longest in the last frame start first (order_by_cost_kernel, once per frame); results do not depend on the order.
     const int blk = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
     const unsigned long long t_begin = b.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int e = blk * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blk * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     double B[12];
     Mat3 Dx, u, F, z;
     ADMM_PROF_T0
@@ -265,9 +266,9 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
 // order (CollisionFloor.hpp:51-58, CollisionSphere.hpp:50-66, CollisionCylinder.hpp:48-66)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) {
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     const int id = b.idx[e];
     const double s = b.w2h2[e];
     double dx[3], u[3], p[3];
@@ -306,9 +307,9 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev
 // Spring, Force.cpp:52-71   (rows: x_a - x_b)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     const int ia = b.idx[2 * (size_t)e], ib = b.idx[2 * (size_t)e + 1];
     const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e], rest_length = b.rest[e];
     double dx[3], u[3], d[3];
@@ -341,9 +342,9 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b,
 // BendForce, BendForce.cpp:131-161   rows (x0-x2, x3-x2, x1-x2)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
     const double a0 = b.rest[(size_t)0 * n + e], a1 = b.rest[(size_t)1 * n + e], a3 = b.rest[(size_t)3 * n + e];
     const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e];
@@ -393,9 +394,9 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, c
 // restatement of Eigen's 3x2 JacobiSVD (local_math.hpp svd32).
 template <int MODE>
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
-    if (e >= n) return;
+    if (e >= b.e1) return;
     const int i0 = b.idx[4 * (size_t)e], i1 = b.idx[4 * (size_t)e + 1], i2 = b.idx[4 * (size_t)e + 2];
     double B[6];
 #pragma unroll

@@ -256,6 +256,38 @@ def test_backward_kernel_shapes(pkg, monkeypatch, nw, cw2, small_nw):
         assert np.array_equal(x, s.solve_only(b))
 
 
+@pytest.mark.parametrize("groups,scene", [("2", "bar"), ("3", "bar"), ("2", "mixed")])
+def test_pipelined_groups_bitwise_equal_serial_launch(pkg, monkeypatch, groups, scene):
+    """ADMM_HIP_PIPE=G (opt-in experiment): elements and elimination subtrees in G groups, every group's chain
+    bwd -> local step -> rhs -> fwd on its own stream, joined only at the top of the tree (System.cpp:51-67 is the loop being
+    re-ordered).  The pipelined frame (multi-stream, captured as graphs, or eager) must equal the SERIAL launch of the same
+    group-major layout bit for bit -- same kernels on the same data, only the interleaving differs -- and the default layout up
+    to the order of the per-node sums of the right-hand side."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+
+    def make():
+        if scene == "bar":
+            s = pkg.make_bar_system(8, 8, 40, kind=KIND["TET_STVK"], device_id=0)
+        else:
+            s, _ = pkg.make_mixed_system(8, 8, 24, 24, 20)
+        s.initialize()
+        return s
+    ref = make()                                   # default layout
+    monkeypatch.setenv("ADMM_HIP_PIPE", groups)
+    piped = make()
+    serial = make(); serial.enable_timing(1)       # timing events around every phase: group after group on one stream
+    monkeypatch.setenv("ADMM_HIP_PIPE_GRAPH", "0")
+    eager = make()
+    for frame in range(3):
+        for s in (ref, piped, serial, eager):
+            s.step(6)
+        xp = piped.m_x
+        assert np.isfinite(xp).all()
+        assert np.array_equal(xp, serial.m_x), frame
+        assert np.array_equal(xp, eager.m_x), frame
+        assert np.abs(xp - ref.m_x).max() < 2e-5       # (the truncated prox amplifies the re-ordered sums within a frame, DESIGN 4.6)
+
+
 @pytest.mark.parametrize("dims,leaf", [((6, 5, 17), "16"), ((8, 8, 40), "0"), ((12, 12, 30), "64")])
 def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
     """The numeric multifrontal factorization on the GPU (csrc/factor_dev.hpp: MFMA fp64 products per 64-column block, block
