@@ -37,6 +37,19 @@ def build(force=False, verbose=False, extra_hip_flags=(), out=None, tag=""):
     global OUT
     out = out or OUT
     os.makedirs(OBJ, exist_ok=True)
+    # one builder at a time (the ranks of a multi-process launch all come through here): the others wait on the lock and then
+    # find everything up to date; the library is linked under a temporary name and renamed into place, so a process that is
+    # dlopen'ing it never sees a half-written file
+    import fcntl
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, extra_hip_flags, out, tag)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, extra_hip_flags, out, tag):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers += [os.path.join(HERE, "..", "include", f) for f in ("admm_hip.h", "admm_kinds.h")]
@@ -58,10 +71,12 @@ def build(force=False, verbose=False, extra_hip_flags=(), out=None, tag=""):
             subprocess.check_call(full, stderr=subprocess.DEVNULL if not verbose else None)
             rebuilt = True
     if rebuilt or not os.path.exists(out):
-        full = [hipcc, "--offload-arch=gfx950", "-shared", "-o", out] + objs + ["-lgomp"]
+        tmp = "%s.tmp.%d" % (out, os.getpid())
+        full = [hipcc, "--offload-arch=gfx950", "-shared", "-o", tmp] + objs + ["-lgomp"]
         if verbose:
             print(" ".join(full))
         subprocess.check_call(full, stderr=subprocess.DEVNULL if not verbose else None)
+        os.replace(tmp, out)
     return out
 
 

@@ -496,7 +496,9 @@ int device_factorize(admm_hip_ctx *ctx) {
     for (int s = 0; s < ns; ++s) { const int64_t f = F.sn[s].ncols + F.sn[s].nrows; foff[s] = ftot; ftot += f * f; }
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if ((double)ftot * 8.0 > 0.8 * (double)free_b) return ADMM_DEVFACTOR_NOFIT;
+    // the fronts plus this call's side buffers (A's values and scatter maps: ~20 bytes per entry; row maps; the task records)
+    const double side_b = 20.0 * (double)ctx->A.val.size() + 4.0 * (double)F.rows.size() + 64.0 * 1024.0 * 1024.0;
+    if ((double)ftot * 8.0 + side_b > 0.8 * (double)free_b) return ADMM_DEVFACTOR_NOFIT;
     // original entries: destination in the fronts, source in A
     SymCSC PA;
     permuted_lower(ctx->A, F, PA, true);
@@ -534,7 +536,9 @@ int device_factorize(admm_hip_ctx *ctx) {
     GemmTask *d_gemm = nullptr; PotrfTask *d_potrf = nullptr; ExtendTask *d_ext = nullptr;
     auto cleanup = [&]() { for (void *p : {(void *)d_fronts, (void *)d_aval, (void *)d_adst, (void *)d_asrc, (void *)d_rel, (void *)d_fail, (void *)d_gemm, (void *)d_potrf, (void *)d_ext}) if (p) (void)hipFree(p); };
     if (hipMalloc(&d_fronts, sizeof(double) * std::max<int64_t>(ftot, 1)) != hipSuccess) { (void)hipGetLastError(); return ADMM_DEVFACTOR_NOFIT; }
-#define DF_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(ctx, ADMM_ERR_HIP, "device factorization: %s: %s", #call, hipGetErrorString(e_)); } } while (0)
+    // an allocation that fails is "does not fit" (clean up, clear HIP's error, let the caller factor on the host); anything else is an error
+#define DF_CHK(call) do { hipError_t e_ = (call); if (e_ == hipErrorOutOfMemory) { cleanup(); (void)hipGetLastError(); return ADMM_DEVFACTOR_NOFIT; } \
+                          if (e_ != hipSuccess) { cleanup(); return fail(ctx, ADMM_ERR_HIP, "device factorization: %s: %s", #call, hipGetErrorString(e_)); } } while (0)
     hipStream_t st = ctx->stream;
     DF_CHK(hipMemsetAsync(d_fronts, 0, sizeof(double) * std::max<int64_t>(ftot, 1), st));
     DF_CHK(hipMemsetAsync(ctx->d_panels, 0, sizeof(double) * std::max<int64_t>(F.panels_size, 1), st));

@@ -526,6 +526,9 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
     double width = stpmax - stpmin, width1 = 2 * width;
     double stx = 0.0, fx = finit, dgx = dginit, sty = 0.0, fy = finit, dgy = dginit;
     double stmin = 0.0, stmax = 0.0;
+#if ADMM_PROF_ON
+    V3 prof_px = x;
+#endif
     for (;;) {
         if (brackt) { stmin = smin(stx, sty); stmax = smax(stx, sty); }
         else { stmin = stx; stmax = stp + xtrapf * (stp - stx); }
@@ -533,6 +536,17 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         stp = smin(stp, stpmax);
         if ((brackt && ((stp <= stmin) | (stp >= stmax))) | (nfev >= maxfev - 1) | (infoc == 0) | (brackt & (stmax - stmin <= xtol * stmax))) stp = stx;
         V3 xn; xn.a = x.a + stp * s.a; xn.b = x.b + stp * s.b; xn.c = x.c + stp * s.c;
+#if ADMM_PROF_ON && defined(__HIP_DEVICE_COMPILE__)
+        {   // how many evaluations happen at a point that was evaluated just before (the previous trial point or the base point)?
+            const bool rep = (xn.a == prof_px.a && xn.b == prof_px.b && xn.c == prof_px.c) || (xn.a == x.a && xn.b == x.b && xn.c == x.c);
+            const unsigned long long act = __ballot(1), reps = __ballot(rep);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+                atomicAdd(&g_tet_prof[18], (unsigned long long)__popcll(act)); atomicAdd(&g_tet_prof[20], (unsigned long long)__popcll(reps));
+                atomicAdd(&g_tet_prof[22], 1ull); if (reps == act) atomicAdd(&g_tet_prof[24], 1ull);
+            }
+            prof_px = xn;
+        }
+#endif
         f = prob.value(xn);
         g = prob.gradient(xn);
         g_out = g; evaluated = true;

@@ -269,12 +269,25 @@ def _check_dillo(out, g, release):
         ref, env, frames = g["x_frames"], g["ulp_sensitivity"], range(nf)
     else:
         ref, env, frames = g["x_release"], g["ulp_sensitivity_release"], [int(f) for f in g["release_keep"]]
-    # the reference's own resolution: its trajectory moves by `env` when its start moves by 1-3 ulps (truncated L-BFGS +
-    # Armadillo contacts: chaotic from frame 4 on); 20 x that while it is tiny, 5 x once it is macroscopic
-    for k, f in enumerate(frames):
-        e = float(env[k]); bound = 20.0 * e if e < 1e-3 else 5.0 * e
+    # The reference's own resolution: its trajectory moves by `env` when its start moves by 1-3 ulps (truncated L-BFGS +
+    # Armadillo contacts).  Two separate claims:
+    #  (1) PRE-CHAOS frames (the reference still agrees with itself to < 1e-4; frames 0-2 here): a tight bound, 3 x the reference's
+    #      own sensitivity (measured: 0.5-1.2 x) -- a regression of the solver shows up HERE and cannot hide behind (2);
+    #  (2) frames after the reference's own bifurcation (its 1-ulp twin is 5e-3 .. 3e-2 away): these assert the same macroscopic
+    #      motion inside 5 x that chaotic envelope (measured: 0.3-1.5 x) and finiteness -- no more can be asked of ANY solver
+    #      whose rounding differs from the reference's.
+    tight = [(k, f) for k, f in enumerate(frames) if float(env[k]) < 1e-4]
+    assert release >= 0 or len(tight) >= 3
+    for k, f in tight:
         err = np.abs(X[f] - ref[k]).max()
-        assert err < max(bound, 1e-9), (f, err, e)
+        assert err < 3.0 * float(env[k]), ("pre-chaos frame", f, err, float(env[k]))
+    for k, f in enumerate(frames):
+        e = float(env[k])
+        err = np.abs(X[f] - ref[k]).max()
+        if os.environ.get("ADMM_TEST_VERBOSE"):
+            print("dillo frame %3d: |x - x_ref| %.3e   reference's own 1-3 ulp sensitivity %.3e" % (f, err, e))
+        if e >= 1e-4:
+            assert err < 5.0 * e, ("chaotic frame", f, err, e)
     if release >= 0:
         assert np.abs(raw[nf * dof:] - g["hand_cp_after_release"]).max() < 5.0 * float(env[-1])      # a released anchor follows its node
     else:

@@ -854,6 +854,24 @@ def test_explicit_forces(pkg):
         for c in range(3):
             vexp[t[c]] += force
     assert np.abs(v - vexp).max() < 1e-13 * max(1.0, np.abs(vexp).max())
+    # ... and directly against the ORACLE's wind path (orc wind_project, the restatement of ExplicitForce.cpp:42-98 in serial
+    # triangle order that tests/test_oracle_vs_ref.py pins to the compiled reference): velocities after the explicit forces of a
+    # frame, then whole frames with the wind blowing while the cloth moves (the wind reads the moving x and v every frame)
+    ow = build(Oracle()); ow.settings(0.04, 0)
+    ow.add_explicit(1, [10.0, 0.0, 2.0], tris)
+    assert ow.initialize()
+    ow.step()
+    assert np.abs(s.m_v - ow.v).max() < 1e-13 * max(1.0, np.abs(ow.v).max())
+    assert np.abs(s.m_x - ow.x).max() < 1e-13
+    s3 = build(pkg.System(device_id=0)); s3.set_timestep(0.04)
+    s3.add_explicit(pkg.EXPLICIT["WIND"], [10.0, 0.0, 2.0], tris)
+    s3.initialize()
+    o3 = build(Oracle()); o3.settings(0.04, 10)
+    o3.add_explicit(1, [10.0, 0.0, 2.0], tris)
+    assert o3.initialize()
+    for f in range(4):
+        s3.step(10); o3.step()
+        assert np.abs(s3.m_x - o3.x).max() < 1e-9 and np.abs(s3.m_v - o3.v).max() < 1e-8, f
     s.set_gravity(w, [0.0, 0.0, 0.0])            # direction is host-mutable (windyflag.cpp:141-152)
     s.step(5)
     assert np.isfinite(s.m_x).all()

@@ -38,6 +38,8 @@ for f in range(frames):
         print("   %%-40s %%6.1f %%%%" %% (nm, 100 * v[i] / tot))
     for nm, i in (("Jacobi sweeps", 8), ("Jacobi rotations", 10), ("L-BFGS outer iterations", 12), ("line-search evaluations", 14)):
         print("   %%-28s mean per tet %%6.2f   mean of wave maxima %%6.2f   -> lane efficiency %%.2f" %% (nm, v[i] / (64 * waves), v[i + 1] / (64 * waves), v[i] / max(v[i + 1], 1)))
+    print("   line-search evaluations at a point evaluated just before (previous trial point or the base point): %%.1f %%%% of the lane evaluations; "
+          "%%.1f %%%% of the wave-level evaluation steps have ONLY such lanes active" %% (100 * v[20] / max(v[18], 1), 100 * v[24] / max(v[22], 1)))
     h = v[32:64]; hw = v[64:96]
     print("   line-search evaluations per tet (%%):   " + " ".join("%%d:%%.1f" %% (k, 100 * h[k] / max(h.sum(), 1)) for k in range(32) if h[k]))
     print("   wave maximum of the same (%%):          " + " ".join("%%d:%%.1f" %% (k, 100 * hw[k] / max(hw.sum(), 1)) for k in range(32) if hw[k]))
