@@ -53,6 +53,11 @@ struct Batch {
     double *d_u = nullptr, *d_z = nullptr, *d_state = nullptr, *d_targets = nullptr;
     double *d_dx_override = nullptr, *d_dx_buf = nullptr; // parity tests only
     double *d_u_prev = nullptr, *d_z_prev = nullptr, *d_G = nullptr;   // residual tracking only
+    // tets: the corners' right-hand-side shares are summed per node inside every 64-tet block (LDS) before they go to the slots:
+    // one slot per (block, node) instead of one per corner (project_tet_kernel's epilogue)
+    bool prered = false;
+    unsigned int *d_pos4 = nullptr; int *d_bn_ptr = nullptr, *d_bn_dst = nullptr; unsigned short *d_bn_end = nullptr;
+    double *d_res_partial = nullptr; bool res_fused = false;           // tets: residuals come out of the projection kernel itself (one |r|^2 partial per 64-tet block)
     std::vector<double> G;                // [12][n_local] selector block per element, corners in device order
     // ---- ADMM_KIND_GENERIC (user-defined forces): selector rows as CSR over the batch's rows
     std::vector<int64_t> g_elem_row;      // [n_total + 1] first batch row of every element
@@ -147,6 +152,7 @@ struct admm_hip_ctx {
     // runs on its own stream and only the top of the tree joins them, so one group's latency-bound sweeps run under another
     // group's VALU-bound local step.  The element arrays of every batch are group-major (Batch::grp_ptr); without the pipeline
     // (timed iterations, residual tracking) the same layout is launched group after group on one stream: bitwise the same result.
+    bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
     int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
     std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
     std::vector<std::vector<std::pair<int, int> > > pipe_nodes;      // [G + 1] node ranges (factor order) of every group's subtrees; last = the top
@@ -185,6 +191,8 @@ struct admm_hip_ctx {
     double tol_r = 0.0, tol_s = 0.0; int check_every = 1;
     double *d_res = nullptr; int res_cap = 0, res_n = 0;      // [2 * res_cap]: r^2, s^2 per iteration
     double *d_res_slots = nullptr, *d_res_s = nullptr, *d_res_partial = nullptr; int res_partial_n = 0;
+    // one GPU: the reductions behind the local step (gather of s, norms) run on a side stream under the forward sweep
+    hipStream_t res_stream = nullptr; hipEvent_t res_ev_local = nullptr, res_ev_done = nullptr; bool res_pending = false;
     // user-defined forces: host round trip per ADMM iteration (see admm_hip_add_generic_batch)
     admm_hip_project_fn project_hook = nullptr; void *project_user = nullptr;
     int64_t n_gen_rows = 0;
@@ -1029,6 +1037,13 @@ int upload_factor(admm_hip_ctx *ctx) {
     return ADMM_OK;
 }
 
+// is local element `el` the last one of its 64-element launch block?  (blocks restart at every pipeline group's first element)
+static bool block_end(const Batch &b, int el) {
+    int base = 0;
+    if (!b.grp_ptr.empty()) { size_t g = 0; while (g + 2 < b.grp_ptr.size() && el >= b.grp_ptr[g + 1]) ++g; base = b.grp_ptr[g]; if (el + 1 == b.grp_ptr[g + 1]) return true; }
+    return (el - base) % admm_dev::LOCAL_BLOCK == admm_dev::LOCAL_BLOCK - 1;
+}
+
 int upload_all(admm_hip_ctx *ctx) {
     const double t0 = now_s();
     const int n = ctx->n_nodes;
@@ -1067,14 +1082,27 @@ int upload_all(admm_hip_ctx *ctx) {
         if (b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK)
             for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
         b.corner_perm.assign((size_t)b.n_total * nn, 0);
+        b.prered = ctx->tet_prered && b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK;
+        std::vector<int> blk_nodes;       // prered: the nodes of the current 64-tet block
         for (int el = 0; el < b.n_local; ++el) {
             const int e = b.local[el];
             const int *id = b.idx.data() + (size_t)e * nn;
             int ord[4] = {0, 1, 2, 3};
             if (sort_corners) std::stable_sort(ord, ord + nn, [&](int a, int c) { return id[a] < id[c]; });
-            for (int c = 0; c < nn; ++c) { b.corner_perm[(size_t)e * nn + c] = ord[c]; inc_ptr[F.iperm[id[ord[c]]] + 1]++; }
+            for (int c = 0; c < nn; ++c) {
+                b.corner_perm[(size_t)e * nn + c] = ord[c];
+                if (b.prered) blk_nodes.push_back(F.iperm[id[ord[c]]]); else inc_ptr[F.iperm[id[ord[c]]] + 1]++;
+            }
+            if (b.prered && (block_end(b, el) || el + 1 == b.n_local)) {      // one slot per distinct node of the block
+                std::sort(blk_nodes.begin(), blk_nodes.end());
+                blk_nodes.erase(std::unique(blk_nodes.begin(), blk_nodes.end()), blk_nodes.end());
+                for (int pn : blk_nodes) inc_ptr[pn + 1]++;
+                slot += (int64_t)blk_nodes.size();
+                blk_nodes.clear();
+            }
         }
-        slot += (int64_t)b.n_local * nn; nloc += b.n_local;
+        if (!b.prered) slot += (int64_t)b.n_local * nn;
+        nloc += b.n_local;
     }
     int64_t maxdeg = 0;
     for (int i = 0; i < n; ++i) { maxdeg = std::max(maxdeg, inc_ptr[i + 1]); inc_ptr[i + 1] += inc_ptr[i]; }
@@ -1132,6 +1160,13 @@ int upload_all(admm_hip_ctx *ctx) {
         std::vector<int> idx((size_t)std::max(nl, 1) * ist, 0), dst((size_t)std::max(nl, 1) * ist, 0);
         b.G.assign((size_t)12 * std::max(nl, 1), 0.0);
         std::vector<double> rest((size_t)12 * std::max(nl, 1), 0.0), par((size_t)std::max(np, 1) * std::max(nl, 1), 0.0), w2h2(std::max(nl, 1)), kbl(std::max(nl, 1)), w2(std::max(nl, 1));
+        // prered: per block, the corners sorted by (node, lane, corner) -> pos4 (where a corner's share goes in the block's LDS
+        // staging, one byte per corner), and per distinct node an entry (slot, end of its run in the staging)
+        std::vector<unsigned int> pos4(b.prered ? (size_t)std::max(nl, 1) : 0, 0u);
+        std::vector<int> bn_ptr(1, 0), bn_dst; std::vector<unsigned short> bn_end;
+        struct Corner { int pn; unsigned short lc; };      // lc = lane * 4 + corner
+        std::vector<Corner> blk_c;
+        int blk_first = 0;
         for (int el = 0; el < nl; ++el) {
             const int e = b.local[el];
             const int *id = b.idx.data() + (size_t)e * nn;
@@ -1139,8 +1174,24 @@ int upload_all(admm_hip_ctx *ctx) {
             for (int c = 0; c < nn; ++c) {
                 const int pn = F.iperm[id[ord[c]]];
                 idx[(size_t)el * ist + c] = pn;
+                if (b.prered) { blk_c.push_back({pn, (unsigned short)((el - blk_first) * 4 + c)}); continue; }
                 const int64_t r = inc_pos[pn]++;
                 dst[(size_t)el * ist + c] = ctx->slot_stride ? (int)((r - inc_ptr[pn]) * ctx->slot_stride + pn) : (int)r;
+            }
+            if (b.prered && (block_end(b, el) || el + 1 == nl)) {
+                std::stable_sort(blk_c.begin(), blk_c.end(), [](const Corner &x, const Corner &y) { return x.pn < y.pn || (x.pn == y.pn && x.lc < y.lc); });
+                for (size_t k = 0; k < blk_c.size(); ++k) {
+                    const int lane = blk_c[k].lc >> 2, c = blk_c[k].lc & 3;
+                    pos4[(size_t)blk_first + lane] |= (unsigned int)k << (8 * c);
+                    if (k + 1 == blk_c.size() || blk_c[k + 1].pn != blk_c[k].pn) {
+                        const int pn = blk_c[k].pn;
+                        const int64_t r = inc_pos[pn]++;
+                        bn_dst.push_back(ctx->slot_stride ? (int)((r - inc_ptr[pn]) * ctx->slot_stride + pn) : (int)r);
+                        bn_end.push_back((unsigned short)(k + 1));
+                    }
+                }
+                bn_ptr.push_back((int)bn_dst.size());
+                blk_c.clear(); blk_first = el + 1;
             }
             const double *R = &b.rest[(size_t)e * 12];
             if (b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) {
@@ -1161,6 +1212,8 @@ int upload_all(admm_hip_ctx *ctx) {
             w2h2[el] = (ctx->dt * ctx->dt) * (w * w);
             kbl[el] = b.params[(size_t)e * np] * b.measure[e];
         }
+        b.d_pos4 = nullptr; b.d_bn_ptr = nullptr; b.d_bn_dst = nullptr; b.d_bn_end = nullptr;
+        if (b.prered) { TRY(upload(ctx, &b.d_pos4, pos4)); TRY(upload(ctx, &b.d_bn_ptr, bn_ptr)); TRY(upload(ctx, &b.d_bn_dst, bn_dst)); TRY(upload(ctx, &b.d_bn_end, bn_end)); }
         TRY(upload(ctx, &b.d_idx, idx)); TRY(upload(ctx, &b.d_dst, dst)); TRY(upload(ctx, &b.d_rest, rest)); TRY(upload(ctx, &b.d_par, par));
         TRY(upload(ctx, &b.d_w2h2, w2h2)); TRY(upload(ctx, &b.d_kblend, kbl)); TRY(upload(ctx, &b.d_w2, w2));
         TRY(dalloc(ctx, &b.d_u, (size_t)rows * std::max(nl, 1))); TRY(dalloc(ctx, &b.d_z, (size_t)rows * std::max(nl, 1)));
@@ -1244,6 +1297,8 @@ BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     d.fslot = ctx->d_fslot; d.dst = b.d_dst; d.targets = b.d_targets; d.active = b.d_active;
     d.dx_override = b.d_dx_override;
     d.order = b.d_order; d.cost = b.d_cost;
+    d.res_slots = ctx->d_res_slots; d.res_partial = b.d_res_partial;
+    d.pos4 = b.d_pos4; d.bn_ptr = b.d_bn_ptr; d.bn_dst = b.d_bn_dst; d.bn_end = b.d_bn_end;
     return d;
 }
 
@@ -1269,7 +1324,7 @@ void tet_trace_next(hipStream_t st) {
 #endif
 // `group` >= 0 (pipeline groups, Batch::grp_ptr): only that group's elements of every batch, on stream `st`; group < 0 with a
 // group-major layout: group after group on one stream (the serial launch of the same layout)
-int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStream_t st = nullptr) {
+int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStream_t st = nullptr, bool track = false) {
     using namespace admm_dev;
     if (!st) st = ctx->stream;
     bool skip_next = false;
@@ -1286,7 +1341,10 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
             d.e0 = b.grp_ptr[g]; d.e1 = b.grp_ptr[g + 1];
             if (d.e1 == d.e0) continue;
             if (d.order) { d.order += b.grp_blk[g]; d.cost += b.grp_blk[g]; }
+            if (d.res_partial) d.res_partial += b.grp_blk[g];
+            if (d.bn_ptr) d.bn_ptr += b.grp_blk[g];
         }
+        const bool trk = track && b.res_fused;
         dim3 grid((d.e1 - d.e0 + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
         const double *x = ctx->d_xcur;
         // an anchor batch right behind a tet batch rides along in the tet launch (project_tet_kernel's tail)
@@ -1302,16 +1360,17 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
 #ifdef ADMM_TET_PROFILE
             tet_trace_next(st);
 #endif
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<0, 5>), grid, block, 0, st, d, x, tail, tail_block0);
-            else hipLaunchKernelGGL((project_tet_kernel<0, 10>), grid, block, 0, st, d, x, tail, tail_block0);
+#define ADMM_TET(K, MM) do { if (trk) hipLaunchKernelGGL((project_tet_kernel<K, MM, true>), grid, block, 0, st, d, x, tail, tail_block0); \
+                            else hipLaunchKernelGGL((project_tet_kernel<K, MM, false>), grid, block, 0, st, d, x, tail, tail_block0); } while (0)
+            if (max_lbfgs_iters(b) <= 5) ADMM_TET(0, 5); else ADMM_TET(0, 10);
             break;
         case ADMM_KIND_TET_STVK:
-            if (max_lbfgs_iters(b) <= 5) hipLaunchKernelGGL((project_tet_kernel<1, 5>), grid, block, 0, st, d, x, tail, tail_block0);
-            else hipLaunchKernelGGL((project_tet_kernel<1, 10>), grid, block, 0, st, d, x, tail, tail_block0);
+            if (max_lbfgs_iters(b) <= 5) ADMM_TET(1, 5); else ADMM_TET(1, 10);
             break;
-        case ADMM_KIND_TET_LINEAR: hipLaunchKernelGGL((project_tet_kernel<2, 1>), grid, block, 0, st, d, x, tail, tail_block0); break;
-        case ADMM_KIND_TET_VOLUME: hipLaunchKernelGGL((project_tet_kernel<3, 1>), grid, block, 0, st, d, x, tail, tail_block0); break;
-        case ADMM_KIND_ANCHOR: hipLaunchKernelGGL(project_anchor_kernel, grid, block, 0, st, d, x); break;
+        case ADMM_KIND_TET_LINEAR: ADMM_TET(2, 1); break;
+        case ADMM_KIND_TET_VOLUME: ADMM_TET(3, 1); break;
+#undef ADMM_TET
+        case ADMM_KIND_ANCHOR: if (trk) hipLaunchKernelGGL(project_anchor_kernel<true>, grid, block, 0, st, d, x); else hipLaunchKernelGGL(project_anchor_kernel<false>, grid, block, 0, st, d, x); break;
         case ADMM_KIND_SPRING: hipLaunchKernelGGL(project_spring_kernel, grid, block, 0, st, d, x); break;
         case ADMM_KIND_BEND: hipLaunchKernelGGL(project_bend_kernel, grid, block, 0, st, d, x); break;
         case ADMM_KIND_TRI_STRAIN: hipLaunchKernelGGL(project_tri_kernel<0>, grid, block, 0, st, d, x); break;
@@ -1586,7 +1645,13 @@ int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
                 continue;
             }
             const int rows = ADMM_KIND_ROWS[b.kind], nl = std::max(b.n_local, 1);
-            TRY(dalloc(ctx, &b.d_u_prev, (size_t)rows * nl)); TRY(dalloc(ctx, &b.d_z_prev, (size_t)rows * nl));
+            // (ADMM_HIP_RES_UNFUSED=1: the separate passes, for comparison; not for pre-reduced tet batches, which have no per-corner slots)
+            b.res_fused = ((b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) || b.kind == ADMM_KIND_ANCHOR) && (b.prered || getenv("ADMM_HIP_RES_UNFUSED") == nullptr);
+            if (b.res_fused) {      // the tet kernels produce their residuals themselves: no snapshots, one partial per 64-tet block
+                const int nblk = b.grp_blk.empty() ? (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK : std::max(b.grp_blk.back(), 1);
+                TRY(dalloc(ctx, &b.d_res_partial, (size_t)nblk));
+                HIPCHK(hipMemset(b.d_res_partial, 0, sizeof(double) * (size_t)nblk));
+            } else { TRY(dalloc(ctx, &b.d_u_prev, (size_t)rows * nl)); TRY(dalloc(ctx, &b.d_z_prev, (size_t)rows * nl)); }
             TRY(upload(ctx, &b.d_G, b.G));
             slots += (int64_t)b.n_local * ADMM_KIND_NODES[b.kind]; maxn = std::max(maxn, b.n_local);
         }
@@ -1615,11 +1680,19 @@ int residual_snapshot(admm_hip_ctx *ctx, bool first_iteration) {
         if (!b.n_local || b.kind == ADMM_KIND_GENERIC) continue;
         const int rows = ADMM_KIND_ROWS[b.kind];
         const size_t bytes = sizeof(double) * (size_t)rows * b.n_local;
-        HIPCHK(hipMemcpyAsync(b.d_u_prev, b.d_u, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (b.res_fused) {     // z_prev is the kernel's own previous output; only the frame's warm start has to be put there
+            if (first_iteration)
+                hipLaunchKernelGGL(admm_dev::residual_dx_kernel, dim3((b.n_local + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK), dim3(admm_dev::RES_BLOCK), 0, ctx->stream,
+                                   b.n_local, ADMM_KIND_NODES[b.kind], rows / 3, idx_stride(b.kind), b.d_idx, b.d_G, ctx->d_x, b.d_z);
+            continue;
+        }
+        const int64_t cnt = (int64_t)rows * b.n_local;      // one launch instead of two device-to-device copies (each a ~10 us operation whatever its size)
+        hipLaunchKernelGGL(admm_dev::residual_snapshot_kernel, dim3((unsigned)((cnt + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK)), dim3(admm_dev::RES_BLOCK), 0, ctx->stream,
+                           cnt, (const double *)b.d_u, (const double *)b.d_z, b.d_u_prev, b.d_z_prev, first_iteration ? 0 : 1);
         if (first_iteration)   // the reference warm-starts curr_z = D * m_x before the loop (System.cpp:43)
             hipLaunchKernelGGL(admm_dev::residual_dx_kernel, dim3((b.n_local + admm_dev::RES_BLOCK - 1) / admm_dev::RES_BLOCK), dim3(admm_dev::RES_BLOCK), 0, ctx->stream,
                                b.n_local, ADMM_KIND_NODES[b.kind], rows / 3, idx_stride(b.kind), b.d_idx, b.d_G, ctx->d_x, b.d_z_prev);
-        else HIPCHK(hipMemcpyAsync(b.d_z_prev, b.d_z, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        (void)bytes;
     }
     return ADMM_OK;
 }
@@ -1629,6 +1702,21 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     const int n3 = 3 * ctx->n_nodes;
     double *r2 = ctx->d_res + 2 * (size_t)it, *s2 = r2 + 1;
     bool first = true;
+    // everything below only READS what the local step left behind (u, z, the s slots, the |r|^2 partials): with one rank and no
+    // host-side user rows it goes to a side stream and runs under the forward sweep; residual_wait() orders the next writer behind it
+    hipStream_t main_stream = ctx->stream;
+    bool side = ctx->world == 1 && !ctx->n_gen_rows;
+    if (const char *e = getenv("ADMM_HIP_RES_SIDE")) side = side && atoi(e) != 0;
+    if (side) {
+        if (!ctx->res_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->res_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->res_ev_local, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->res_ev_done, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ctx->res_ev_local, main_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->res_stream, ctx->res_ev_local, 0));
+    }
+    struct StreamSwap { admm_hip_ctx *c; hipStream_t keep; ~StreamSwap() { c->stream = keep; } } swap{ctx, main_stream};
+    if (side) ctx->stream = ctx->res_stream;
     if (ctx->n_gen_rows) {      // user rows: |r|^2 of this rank's rows on the host, z - z_prev to the device for the dual residual
         double r2h = 0.0;
         for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC)
@@ -1649,6 +1737,12 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     }
     for (Batch &b : ctx->batches) {
         if (!b.n_local || b.kind == ADMM_KIND_GENERIC) continue;
+        if (b.res_fused) {     // |r|^2 partials and the s slots were written by the projection kernel
+            const int nblk = b.grp_blk.empty() ? (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK : b.grp_blk.back();
+            hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nblk, (const double *)b.d_res_partial, r2, first ? 0 : 1);
+            first = false;
+            continue;
+        }
         const int nb = (b.n_local + RES_BLOCK - 1) / RES_BLOCK, rows = ADMM_KIND_ROWS[b.kind];
         hipLaunchKernelGGL(residual_primal_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, b.n_local, rows, b.d_u, b.d_u_prev, b.d_w2, ctx->d_res_partial);
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, r2, first ? 0 : 1);
@@ -1666,6 +1760,13 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, n3, ctx->d_res_s, ctx->d_res_partial);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, s2, 0);
     HIPCHK(hipGetLastError());
+    if (side) { HIPCHK(hipEventRecord(ctx->res_ev_done, ctx->res_stream)); ctx->res_pending = true; }
+    return ADMM_OK;
+}
+// the side stream's reductions must be through before anything overwrites their inputs (the next snapshot / local step) or reads
+// their results (the convergence test, the end of the frame)
+int residual_wait(admm_hip_ctx *ctx) {
+    if (ctx->res_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->res_ev_done, 0)); ctx->res_pending = false; }
     return ADMM_OK;
 }
 
@@ -1730,6 +1831,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_CW2_MAX")) ctx->bwd_cw2_max_cols = atoi(g);
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_PIPE")) { const int v = atoi(g); if (v >= 2 && v <= 8) { ctx->pipe = v; ctx->groups = v; } }
+    if (const char *g = getenv("ADMM_HIP_PRERED")) ctx->tet_prered = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_CHAIN")) ctx->pipe_chain = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_GRAPH")) ctx->pipe_graph = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_CUMASK")) ctx->pipe_cu_mask = atoi(g);
@@ -1754,6 +1856,9 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
+        if (ctx->res_ev_local) (void)hipEventDestroy(ctx->res_ev_local);
+        if (ctx->res_ev_done) (void)hipEventDestroy(ctx->res_ev_done);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
@@ -1984,6 +2089,9 @@ static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, v
     if (!ctx->host_allreduce) return 1;
     if ((size_t)count > ctx->h_comm_cap) {
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
+        if (ctx->res_ev_local) (void)hipEventDestroy(ctx->res_ev_local);
+        if (ctx->res_ev_done) (void)hipEventDestroy(ctx->res_ev_done);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
@@ -2211,9 +2319,9 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         if (use_graph && ctx->iter_exec && !timed) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
         if (timed) ++ctx->ev_timed;
         TRY(mark(ctx, timed));
-        if (track) TRY(residual_snapshot(ctx, it == 0));
+        if (track) { TRY(residual_wait(ctx)); TRY(residual_snapshot(ctx, it == 0)); }
         TRY(generic_begin(ctx, ctx->d_xcur));
-        TRY(launch_local(ctx));
+        TRY(launch_local(ctx, -1, -1, nullptr, track));
         TRY(generic_finish(ctx));
         TRY(mark(ctx, timed));
         if (track) { TRY(launch_residuals(ctx, it)); ctx->res_n = it + 1; }
@@ -2237,6 +2345,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         iters_done = it + 1;
         if (ctx->tol_r > 0.0 && (it + 1) % ctx->check_every == 0 && it + 1 < admm_iters) {   // convergence test: one round trip
             double rs[2];
+            TRY(residual_wait(ctx));
             HIPCHK(hipMemcpyAsync(rs, ctx->d_res + 2 * (size_t)it, sizeof rs, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (std::sqrt(rs[0]) <= ctx->tol_r && std::sqrt(rs[1]) <= ctx->tol_s) break;
@@ -2244,6 +2353,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     }
     ctx->ev_iters = iters_done;
     if (ctx->timing) ++ctx->timing_frame;
+    if (track) TRY(residual_wait(ctx));
     TRY(mark(ctx));
     TRY(shard_sync_x(ctx));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);

@@ -208,6 +208,13 @@ __global__ __launch_bounds__(RES_BLOCK) void residual_primal_kernel(int n, int r
     for (int off = RES_BLOCK / 2; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+// u, z -> u_prev, z_prev in one launch (kinds whose projection kernel does not track its residuals itself)
+__global__ __launch_bounds__(RES_BLOCK) void residual_snapshot_kernel(int64_t n, const double *__restrict__ u, const double *__restrict__ z, double *__restrict__ up, double *__restrict__ zp, int copy_z) {
+    const int64_t i = (int64_t)blockIdx.x * RES_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    up[i] = u[i];
+    if (copy_z) zp[i] = z[i];
+}
 // per corner c: slot[dst[c]] = sum_r G[c][r] * w2 * (z - z_prev)[3r .. 3r+2]
 __global__ __launch_bounds__(RES_BLOCK) void residual_dual_kernel(int n, int nn, int cols, int ist, const double *__restrict__ z, const double *__restrict__ zp,
                                                                     const double *__restrict__ w2, const double *__restrict__ G, const int *__restrict__ dst,

@@ -61,6 +61,13 @@ struct BatchDev {
     double *targets;       // anchors: [n][3]
     const int *active;     // anchors: [n]
     const double *dx_override; // parity tests: SoA [rows][n] of D_i x to use instead of the gather (NULL in production)
+    // tets with block-level pre-reduction of the RHS shares (NULL: one slot per corner through dst):
+    const unsigned int *pos4;        // [n] four bytes per tet: where corner c's share goes in the block's staging (corners sorted by node)
+    const int *bn_ptr;               // [blocks + 1] the block's node entries
+    const int *bn_dst;               // [entries] slot of the (block, node) sum
+    const unsigned short *bn_end;    // [entries] end of the node's run in the staging (its start = the previous entry's end, 0 for the first)
+    double *res_slots;     // residual tracking fused into the tet kernels (TRACK): per-corner shares of s = D^T W^T W (z - z_prev), same slot layout as fslot
+    double *res_partial;   // ... and per 64-tet block: sum of w^2 |u_new - u_old|^2 (the block's part of |r|^2)
     const int *order;      // tets, large batches: which 64-tet block workgroup i processes (costliest blocks of the last frame first), or NULL
     unsigned int *cost;    // [blocks]: real-time ticks every block took, summed over a frame (feeds `order`), or NULL
 };
@@ -154,12 +161,24 @@ __global__ __launch_bounds__(1024) void order_by_cost_kernel(int n_blocks, unsig
 // ---------------------------------------------------------------------------
 // StaticAnchor / MovingAnchor, AnchorForce.cpp:46-55, 71-89
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const double *__restrict__ x, int e) {
+// Residual tracking fused into a projection kernel (TRACK): the wave's sum of its lanes' w^2 |u_new - u_old|^2 in a fixed butterfly
+// order -> one partial per 64-element block.  Lanes beyond the batch have returned (they form a suffix of the wave), `act` = the
+// lanes still here: a partner that is gone contributes 0.
+__device__ __forceinline__ void track_block_sum(double a, double *partial_slot) {
+    const unsigned long long act = __ballot(1);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(a, off, 64); const bool have = (act >> ((threadIdx.x & 63) ^ off)) & 1ull; a += have ? o : 0.0; }
+    if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act) - 1)) *partial_slot = a;
+}
+
+template <bool TRACK>
+__device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const double *__restrict__ x, int e, int blk) {
     const int n = b.n;
     if (e >= b.e1) return;
     const int id = b.idx[e];
     const double s = b.w2h2[e];
     const bool act = b.active[e] != 0;
+    double r2 = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
@@ -169,24 +188,35 @@ __device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const dou
         if (act) zi = b.targets[3 * (size_t)e + j];
         else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
         const double un = u + (dx - zi);
+        if (TRACK) {      // s: the one corner's share w^2 (z - z_prev); r: w^2 |u_new - u_old|^2
+            const double du = un - u;
+            r2 += du * du;
+            b.res_slots[3 * (size_t)b.dst[e] + j] = 0.0 + 1.0 * (b.w2[e] * (zi - b.z[(size_t)j * n + e]));
+        }
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
         b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
     }
+    if (TRACK) track_block_sum(b.w2[e] * r2, &b.res_partial[blk]);
 }
+template <bool TRACK>
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
-    project_anchor_elem(b, x, b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x);
+    project_anchor_elem<TRACK>(b, x, b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x, (int)blockIdx.x);
 }
 
-template <int KIND, int M>
+template <int KIND, int M, bool TRACK = false>
 #if ADMM_TET_WAVES > 0
 __global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
 #else
 __global__ __launch_bounds__(LOCAL_BLOCK)
 #endif
 void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail, int tail_block0) {
+    // TRACK (admm_hip_enable_residuals / set_tolerance): the primal and dual residuals of the element (reference: described at
+    // System.cpp:64-65, paper Eq. 22-23) come out of the same registers -- r = W (Dx - z) = W (u_new - u_old), and the corners'
+    // shares of s = D^T W^T W (z - z_prev) with z_prev read back from this kernel's own previous output -- instead of two
+    // snapshot copies and two more passes over u and z (+20 % per iteration before).
     // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
     // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
-    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem(tail, x, tail.e0 + ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x); return; }
+    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem<TRACK>(tail, x, tail.e0 + ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x, (int)blockIdx.x - tail_block0); return; }
     // Launch order by cost: a block's time depends on its slowest line search (2-4 or 20 evaluations, spatially clustered); in mesh
     // order the expensive blocks of the 1M-tet bar come last and the launch ends with a 50 us tail of a few hundred waves.  The blocks
     // that took longest in the last frame start first (order_by_cost_kernel, once per frame); results do not depend on the order.
@@ -197,6 +227,7 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
     if (e >= b.e1) return;
     double B[12];
     Mat3 Dx, u, F, z;
+    Mat3 zp;      // TRACK: z of the previous iteration
     ADMM_PROF_T0
     ADMM_TET_STAMP(e, 0);
     tet_load(b, x, e, n, B, Dx, u);
@@ -213,6 +244,14 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         double sa = b.state[(size_t)0 * n + e], sb = b.state[(size_t)1 * n + e], sc = b.state[(size_t)2 * n + e], hs = b.state[(size_t)3 * n + e];
 #endif
         int it = 0;
+        if (TRACK) {
+            auto load_zprev = [&]() {
+#define ADMM_ZP(mm, row) zp.mm = ld_stream(&b.z[(size_t)row * n + e]);
+                ADMM_ZP(m00, 0) ADMM_ZP(m10, 1) ADMM_ZP(m20, 2) ADMM_ZP(m01, 3) ADMM_ZP(m11, 4) ADMM_ZP(m21, 5) ADMM_ZP(m02, 6) ADMM_ZP(m12, 7) ADMM_ZP(m22, 8)
+#undef ADMM_ZP
+            };
+            z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it, load_zprev);
+        } else
         z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it);
 #if ADMM_LOCAL_NT >= 2
         st_stream(&b.state[(size_t)0 * n + e], sa); st_stream(&b.state[(size_t)1 * n + e], sb); st_stream(&b.state[(size_t)2 * n + e], sc); st_stream(&b.state[(size_t)3 * n + e], hs);
@@ -234,7 +273,17 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
     // across the projection saves ~20 VGPRs but not enough for a third wave per SIMD: -2 %.)
     // u += Dx - z ; q = z - u
     Mat3 q;
-#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; st_stream(&b.u[(size_t)row * n + e], un); st_stream(&b.z[(size_t)row * n + e], z.mm); }
+    Mat3 dz; double r2 = 0.0;      // TRACK only
+    if (TRACK) {
+        if (KIND > 1) {
+#define ADMM_ZP(mm, row) zp.mm = ld_stream(&b.z[(size_t)row * n + e]);
+            ADMM_ZP(m00, 0) ADMM_ZP(m10, 1) ADMM_ZP(m20, 2) ADMM_ZP(m01, 3) ADMM_ZP(m11, 4) ADMM_ZP(m21, 5) ADMM_ZP(m02, 6) ADMM_ZP(m12, 7) ADMM_ZP(m22, 8)
+#undef ADMM_ZP
+        }
+        dz.m00 = z.m00 - zp.m00; dz.m10 = z.m10 - zp.m10; dz.m20 = z.m20 - zp.m20; dz.m01 = z.m01 - zp.m01; dz.m11 = z.m11 - zp.m11; dz.m21 = z.m21 - zp.m21;
+        dz.m02 = z.m02 - zp.m02; dz.m12 = z.m12 - zp.m12; dz.m22 = z.m22 - zp.m22;
+    }
+#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (TRACK) { const double du = un - u.mm; r2 += du * du; } st_stream(&b.u[(size_t)row * n + e], un); st_stream(&b.z[(size_t)row * n + e], z.mm); }
     ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
 #undef ADMM_UZ
     const double s = b.w2h2[e];
@@ -246,12 +295,56 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         f[3 * c + 1] = s * ((B[c] * q.m10 + B[c + 4] * q.m11) + B[c + 8] * q.m12);
         f[3 * c + 2] = s * ((B[c] * q.m20 + B[c + 4] * q.m21) + B[c + 8] * q.m22);
     }
-    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
-    double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
-    o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2];       // (read back by rhs_gather_kernel right away: cached stores)
-    o1[0] = f[3]; o1[1] = f[4]; o1[2] = f[5];
-    o2[0] = f[6]; o2[1] = f[7]; o2[2] = f[8];
-    o3[0] = f[9]; o3[1] = f[10]; o3[2] = f[11];
+    double g[12];      // TRACK: corner c's share of s = D^T W^T W (z - z_prev): w^2 * sum_r B(c, r) dz(:, r) (residual_dual_kernel's arithmetic, G = B)
+    if (TRACK) {
+        const double w2 = b.w2[e];
+        const double q0[3] = {w2 * dz.m00, w2 * dz.m10, w2 * dz.m20}, q1[3] = {w2 * dz.m01, w2 * dz.m11, w2 * dz.m21}, q2[3] = {w2 * dz.m02, w2 * dz.m12, w2 * dz.m22};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[3 * c + j] = ((0.0 + B[c] * q0[j]) + B[c + 4] * q1[j]) + B[c + 8] * q2[j];
+        track_block_sum(w2 * r2, &b.res_partial[blk]);      // |r|^2: this block's sum in a fixed butterfly order
+    }
+    if (b.pos4) {
+        // Block-level pre-reduction: the 64 tets of a block touch ~45 distinct nodes with their 256 corners.  Every corner's share
+        // goes to its place in the block's LDS staging (corners sorted by node, then lane, then corner: pos4), then one lane per
+        // distinct node sums the node's run front to back (fixed order: deterministic) and writes ONE 24-byte slot -- 1.1 KB of slot
+        // traffic per block instead of 6 KB of scattered 8-byte stores, and a gather that reads ~6 slots per node instead of ~24.
+        __shared__ double stage[3 * 256];
+        const unsigned int p4 = b.pos4[e];
+        const unsigned long long act = __ballot(1);
+        const int nact = __popcll(act), lane = threadIdx.x & 63;
+        const int q0 = b.bn_ptr[blk], q1 = b.bn_ptr[blk + 1];
+        auto reduce_to = [&](const double (&v)[12], double *slots) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = (p4 >> (8 * c)) & 255;
+                stage[p] = v[3 * c]; stage[256 + p] = v[3 * c + 1]; stage[512 + p] = v[3 * c + 2];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave per block: its own LDS writes are done, no barrier needed
+            for (int i = q0 + lane; i < q1; i += nact) {
+                const int k1 = b.bn_end[i], k0 = (i == q0) ? 0 : (int)b.bn_end[i - 1];
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                for (int k = k0; k < k1; ++k) { a0 += stage[k]; a1 += stage[256 + k]; a2 += stage[512 + k]; }
+                double *o = slots + 3 * (size_t)b.bn_dst[i];
+                o[0] = a0; o[1] = a1; o[2] = a2;
+            }
+        };
+        reduce_to(f, b.fslot);
+        if (TRACK) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); reduce_to(g, b.res_slots); }
+    } else {
+        const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
+        double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
+        o0[0] = f[0]; o0[1] = f[1]; o0[2] = f[2];       // (read back by rhs_gather_kernel right away: cached stores)
+        o1[0] = f[3]; o1[1] = f[4]; o1[2] = f[5];
+        o2[0] = f[6]; o2[1] = f[7]; o2[2] = f[8];
+        o3[0] = f[9]; o3[1] = f[10]; o3[2] = f[11];
+        if (TRACK) {
+            const int dsl[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { double *o = b.res_slots + 3 * (size_t)dsl[c]; o[0] = g[3 * c]; o[1] = g[3 * c + 1]; o[2] = g[3 * c + 2]; }
+        }
+    }
     ADMM_PROF_TIME(5);
 #if ADMM_PROF_ON
     if (threadIdx.x == 0) atomicAdd(&admm_dev::g_tet_prof[16], 1ull);

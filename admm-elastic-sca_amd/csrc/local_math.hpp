@@ -669,8 +669,11 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
 // ---- HyperElasticTet::project on F = Dx_i + u_i, CORE/TetForce.cpp:320-364 ----
 // state: sa,sb,sc = last_prox_result, hess = solver->settings_.init_hess.
 // Returns z (= U diag(sigma) V^T) and the L-BFGS iteration count.
-template <int TYPE, int M>
-ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter, double &sa, double &sb, double &sc, double &hess, int &n_iters) {
+struct NoMid { ADMM_HD void operator()() const {} };
+// `mid` runs between the minimisation and the recomposition U diag(sigma) V^T: the tracking tet kernel requests its z_prev
+// loads there, so that their latency hides under the recomposition instead of stalling the epilogue
+template <int TYPE, int M, class Mid = NoMid>
+ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter, double &sa, double &sb, double &sc, double &hess, int &n_iters, const Mid &mid = Mid()) {
     double s0, s1, s2; Mat3 U, V;
     ADMM_PROF_T0
     oriented_svd(F, s0, s1, s2, U, V);
@@ -686,6 +689,7 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
 #endif
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
     sa = x2.a; sb = x2.b; sc = x2.c;
+    mid();
     ADMM_PROF_TIME(2);
 #if ADMM_PROF_ON
     if (g_tet_trace) { float *t = g_tet_trace + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); t[0] = (float)prof_g0; t[1] = (float)P.prof_nfev; }
