@@ -41,7 +41,7 @@ class Info(C.Structure):
                                          "panel_bytes", "n_supernodes", "n_levels", "max_super_cols", "max_super_rows",
                                          "solve_contrib_rows")] + \
                [(n, C.c_double) for n in ("t_order_s", "t_symbolic_s", "t_numeric_s", "t_upload_s")] + \
-               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")]
+               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")] + [("rhs_slots", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -133,6 +133,7 @@ def lib():
         L.admm_hip_download_state.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
         L.admm_hip_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_keep_z.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         _lib = L
     return _lib
@@ -456,6 +457,10 @@ class System:
         x = np.zeros_like(b)
         self._chk(self.L.admm_hip_debug_panel_solve_host(self.h, _d(b), _d(x)))
         return x
+
+    def keep_z(self, on=True):
+        """admm_hip_keep_z: whether admm_hip_step stores the tet batches' z (read_local) -- off for production frames."""
+        self._chk(self.L.admm_hip_keep_z(self.h, 1 if on else 0))
 
     def enable_timing(self, on=True):
         self._chk(self.L.admm_hip_enable_timing(self.h, int(on)))

@@ -152,6 +152,10 @@ struct admm_hip_ctx {
     // runs on its own stream and only the top of the tree joins them, so one group's latency-bound sweeps run under another
     // group's VALU-bound local step.  The element arrays of every batch are group-major (Batch::grp_ptr); without the pipeline
     // (timed iterations, residual tracking) the same layout is launched group after group on one stream: bitwise the same result.
+    // the tet kernels' z is an output nobody reads back in a plain frame (admm_hip_read_local aside): admm_hip_keep_z(ctx, 0) -- what
+    // the class mirror and the bench do -- stops storing it in admm_hip_step; the parity entry points (local_step_only / local_step_dx)
+    // and residual tracking always store it.  ADMM_HIP_KEEP_Z=0 / 1 overrides.
+    bool keep_z = true, keep_z_user = true;
     bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
     int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
     std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
@@ -191,8 +195,7 @@ struct admm_hip_ctx {
     double tol_r = 0.0, tol_s = 0.0; int check_every = 1;
     double *d_res = nullptr; int res_cap = 0, res_n = 0;      // [2 * res_cap]: r^2, s^2 per iteration
     double *d_res_slots = nullptr, *d_res_s = nullptr, *d_res_partial = nullptr; int res_partial_n = 0;
-    // one GPU: the reductions behind the local step (gather of s, norms) run on a side stream under the forward sweep
-    hipStream_t res_stream = nullptr; hipEvent_t res_ev_local = nullptr, res_ev_done = nullptr; bool res_pending = false;
+
     // user-defined forces: host round trip per ADMM iteration (see admm_hip_add_generic_batch)
     admm_hip_project_fn project_hook = nullptr; void *project_user = nullptr;
     int64_t n_gen_rows = 0;
@@ -1243,6 +1246,7 @@ int upload_all(admm_hip_ctx *ctx) {
         }
     }
     ctx->info.n_elems_local = nloc;
+    ctx->info.rhs_slots = slot;
     if (ctx->slot_stride) slot = maxdeg * n;
     if (slot >= (int64_t)1 << 31) return fail(ctx, ADMM_ERR_UNSUPPORTED, "more than 2^31 RHS slots");
     ctx->n_fslots = slot;
@@ -1292,7 +1296,7 @@ int upload_all(admm_hip_ctx *ctx) {
 
 BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     BatchDev d{};
-    d.n = b.n_local; d.e0 = 0; d.e1 = b.n_local; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
+    d.n = b.n_local; d.e0 = 0; d.e1 = b.n_local; d.keep_z = ctx->keep_z ? 1 : 0; d.idx = b.d_idx; d.rest = b.d_rest; d.par = b.d_par; d.w2h2 = b.d_w2h2; d.kblend = b.d_kblend; d.w2 = b.d_w2;
     d.u = b.d_u; d.z = b.d_z; d.state = b.d_state; d.n_iters = b.d_niters;
     d.fslot = ctx->d_fslot; d.dst = b.d_dst; d.targets = b.d_targets; d.active = b.d_active;
     d.dx_override = b.d_dx_override;
@@ -1350,7 +1354,9 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
         // an anchor batch right behind a tet batch rides along in the tet launch (project_tet_kernel's tail)
         BatchDev tail{}; const int tail_block0 = (int)grid.x;
         const bool is_tet = b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK || b.kind == ADMM_KIND_TET_LINEAR || b.kind == ADMM_KIND_TET_VOLUME;
-        if (is_tet && !grouped && only_batch < 0 && ctx->fuse_anchor_tail && bi + 1 < ctx->batches.size() && ctx->batches[bi + 1].kind == ADMM_KIND_ANCHOR && ctx->batches[bi + 1].n_local > 0) {
+        // (with residual tracking only if both batches track inside their kernels: the tail runs the tet launch's TRACK variant)
+        if (is_tet && !grouped && only_batch < 0 && ctx->fuse_anchor_tail && bi + 1 < ctx->batches.size() && ctx->batches[bi + 1].kind == ADMM_KIND_ANCHOR && ctx->batches[bi + 1].n_local > 0 &&
+            (!track || ctx->batches[bi + 1].res_fused == b.res_fused)) {
             tail = batch_dev(ctx, ctx->batches[bi + 1]);
             grid.x += (ctx->batches[bi + 1].n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
             skip_next = true;
@@ -1417,7 +1423,7 @@ int launch_rhs(admm_hip_ctx *ctx, int group = -1, hipStream_t st = nullptr) {
     if (!st) st = ctx->stream;
     auto range = [&](int a, int e) {
         const int n3 = 3 * (e - a);
-        if (n3 > 0) hipLaunchKernelGGL(admm_dev::rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, a, e, ctx->d_inc_ptr, ctx->slot_stride,
+        if (n3 > 0) hipLaunchKernelGGL(admm_dev::rhs_gather_kernel<false>, dim3((n3 + 255) / 256), dim3(256), 0, st, a, e, ctx->d_inc_ptr, ctx->slot_stride,
                                        ctx->d_fslot, ctx->d_mxbar, ctx->rank == 0 ? 1 : 0, (const unsigned char *)ctx->d_base_mask, ctx->d_y);
     };
     if (group < 0) range(0, ctx->n_nodes);
@@ -1702,21 +1708,6 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     const int n3 = 3 * ctx->n_nodes;
     double *r2 = ctx->d_res + 2 * (size_t)it, *s2 = r2 + 1;
     bool first = true;
-    // everything below only READS what the local step left behind (u, z, the s slots, the |r|^2 partials): with one rank and no
-    // host-side user rows it goes to a side stream and runs under the forward sweep; residual_wait() orders the next writer behind it
-    hipStream_t main_stream = ctx->stream;
-    bool side = ctx->world == 1 && !ctx->n_gen_rows;
-    if (const char *e = getenv("ADMM_HIP_RES_SIDE")) side = side && atoi(e) != 0;
-    if (side) {
-        if (!ctx->res_stream) {
-            HIPCHK(hipStreamCreateWithFlags(&ctx->res_stream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&ctx->res_ev_local, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->res_ev_done, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(ctx->res_ev_local, main_stream));
-        HIPCHK(hipStreamWaitEvent(ctx->res_stream, ctx->res_ev_local, 0));
-    }
-    struct StreamSwap { admm_hip_ctx *c; hipStream_t keep; ~StreamSwap() { c->stream = keep; } } swap{ctx, main_stream};
-    if (side) ctx->stream = ctx->res_stream;
     if (ctx->n_gen_rows) {      // user rows: |r|^2 of this rank's rows on the host, z - z_prev to the device for the dual residual
         double r2h = 0.0;
         for (const Batch &b : ctx->batches) if (b.kind == ADMM_KIND_GENERIC)
@@ -1751,22 +1742,17 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
         first = false;
     }
     if (first) HIPCHK(hipMemsetAsync(r2, 0, sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(rhs_gather_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, 0, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
-    if (ctx->world > 1) {   // s is a sum over all ranks' elements; r^2 is additive
-        TRY(do_allreduce(ctx, ctx->d_res_s, (int64_t)n3));
-        TRY(do_allreduce(ctx, r2, 1));
-    }
     const int nb = (n3 + RES_BLOCK - 1) / RES_BLOCK;
-    hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, n3, ctx->d_res_s, ctx->d_res_partial);
+    static_assert(RES_BLOCK == 256, "the gather's blocks are the norm's partials");
+    if (ctx->world == 1) {      // one rank: the gather of s leaves its blocks' sums of squares behind, no norm pass
+        hipLaunchKernelGGL(rhs_gather_kernel<true>, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, 0, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s, ctx->d_res_partial);
+    } else {                    // s is a sum over all ranks' elements (all-reduced before its norm); r^2 is additive
+        hipLaunchKernelGGL(rhs_gather_kernel<false>, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, 0, ctx->n_nodes, ctx->d_inc_ptr, ctx->slot_stride, ctx->d_res_slots, ctx->d_mxbar, 0, (const unsigned char *)nullptr, ctx->d_res_s);
+        if (ctx->world > 1) { TRY(do_allreduce(ctx, ctx->d_res_s, (int64_t)n3)); TRY(do_allreduce(ctx, r2, 1)); }
+        hipLaunchKernelGGL(norm2_partial_kernel, dim3(nb), dim3(RES_BLOCK), 0, ctx->stream, n3, ctx->d_res_s, ctx->d_res_partial);
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nb, ctx->d_res_partial, s2, 0);
     HIPCHK(hipGetLastError());
-    if (side) { HIPCHK(hipEventRecord(ctx->res_ev_done, ctx->res_stream)); ctx->res_pending = true; }
-    return ADMM_OK;
-}
-// the side stream's reductions must be through before anything overwrites their inputs (the next snapshot / local step) or reads
-// their results (the convergence test, the end of the frame)
-int residual_wait(admm_hip_ctx *ctx) {
-    if (ctx->res_pending) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->res_ev_done, 0)); ctx->res_pending = false; }
     return ADMM_OK;
 }
 
@@ -1832,6 +1818,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_PIPE")) { const int v = atoi(g); if (v >= 2 && v <= 8) { ctx->pipe = v; ctx->groups = v; } }
     if (const char *g = getenv("ADMM_HIP_PRERED")) ctx->tet_prered = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_KEEP_Z")) ctx->keep_z_user = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_CHAIN")) ctx->pipe_chain = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_GRAPH")) ctx->pipe_graph = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_CUMASK")) ctx->pipe_cu_mask = atoi(g);
@@ -1856,9 +1843,6 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
-        if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
-        if (ctx->res_ev_local) (void)hipEventDestroy(ctx->res_ev_local);
-        if (ctx->res_ev_done) (void)hipEventDestroy(ctx->res_ev_done);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
@@ -2089,9 +2073,6 @@ static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, v
     if (!ctx->host_allreduce) return 1;
     if ((size_t)count > ctx->h_comm_cap) {
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
-        if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
-        if (ctx->res_ev_local) (void)hipEventDestroy(ctx->res_ev_local);
-        if (ctx->res_ev_done) (void)hipEventDestroy(ctx->res_ev_done);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
@@ -2275,6 +2256,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     TRY(mark(ctx));
     const bool track = ctx->res_on || ctx->tol_r > 0.0;
     if (track) TRY(ensure_residual_buffers(ctx, admm_iters));
+    ctx->keep_z = ctx->keep_z_user || track;
     if (ctx->n_gen_rows) {      // user-defined forces: curr_z = D * m_x before the loop (System.cpp:43)
         TRY(generic_begin(ctx, ctx->d_x));
         HIPCHK(hipEventSynchronize(ctx->gen_ev));
@@ -2319,7 +2301,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         if (use_graph && ctx->iter_exec && !timed) { HIPCHK(hipGraphLaunch(ctx->iter_exec, ctx->stream)); iters_done = it + 1; continue; }
         if (timed) ++ctx->ev_timed;
         TRY(mark(ctx, timed));
-        if (track) { TRY(residual_wait(ctx)); TRY(residual_snapshot(ctx, it == 0)); }
+        if (track) TRY(residual_snapshot(ctx, it == 0));
         TRY(generic_begin(ctx, ctx->d_xcur));
         TRY(launch_local(ctx, -1, -1, nullptr, track));
         TRY(generic_finish(ctx));
@@ -2345,7 +2327,6 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         iters_done = it + 1;
         if (ctx->tol_r > 0.0 && (it + 1) % ctx->check_every == 0 && it + 1 < admm_iters) {   // convergence test: one round trip
             double rs[2];
-            TRY(residual_wait(ctx));
             HIPCHK(hipMemcpyAsync(rs, ctx->d_res + 2 * (size_t)it, sizeof rs, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (std::sqrt(rs[0]) <= ctx->tol_r && std::sqrt(rs[1]) <= ctx->tol_s) break;
@@ -2353,7 +2334,6 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     }
     ctx->ev_iters = iters_done;
     if (ctx->timing) ++ctx->timing_frame;
-    if (track) TRY(residual_wait(ctx));
     TRY(mark(ctx));
     TRY(shard_sync_x(ctx));
     hipLaunchKernelGGL(epilogue_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, n3, ctx->dt, ctx->d_x, ctx->d_v, ctx->d_xcur);
@@ -2524,9 +2504,23 @@ int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *res
     return ADMM_OK;
 }
 
+int admm_hip_keep_z(admm_hip_ctx *ctx, int on) {
+    if (!ctx) return ADMM_ERR_ARG;
+    if (getenv("ADMM_HIP_KEEP_Z")) return ADMM_OK;      // the environment decides
+    if (ctx->keep_z_user != (on != 0) && ctx->iter_exec) {      // the captured iteration carries the flag in its kernel arguments
+        (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr;
+        if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
+    }
+    ctx->keep_z_user = on != 0;
+    return ADMM_OK;
+}
+
+namespace { struct KeepZ { admm_hip_ctx *c; bool old; explicit KeepZ(admm_hip_ctx *c_) : c(c_), old(c_->keep_z) { c->keep_z = true; } ~KeepZ() { c->keep_z = old; } }; }
+
 int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur) {
     TRY(require_device(ctx));
     if (!x_cur) return ADMM_ERR_ARG;
+    KeepZ kz(ctx);
     TRY(set_nodes(ctx, ctx->d_xcur, x_cur));
     TRY(generic_begin(ctx, ctx->d_xcur));
     TRY(launch_local(ctx));
@@ -2552,6 +2546,7 @@ int admm_hip_local_step_dx(admm_hip_ctx *ctx, int batch, const double *dx) {
     if (!b.d_dx_buf) TRY(dalloc(ctx, &b.d_dx_buf, tmp.size()));
     HIPCHK(hipMemcpy(b.d_dx_buf, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     b.d_dx_override = b.d_dx_buf;
+    KeepZ kz(ctx);
     int rc = launch_local(ctx, batch);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     b.d_dx_override = nullptr;             // production launches never see the override

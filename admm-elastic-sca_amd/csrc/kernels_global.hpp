@@ -129,33 +129,48 @@ __global__ void permute_out_kernel(int n_nodes, const int *__restrict__ perm, co
 #define ADMM_RHS_UNROLL 1
 #endif
 // The launch covers the nodes [node0, node1): all of them, or one pipeline group's node ranges (admm_hip.hip pipe_*).
-__global__ void rhs_gather_kernel(int node0, int node1, const int64_t *__restrict__ inc_ptr, int slot_stride,
+// NORM (residual tracking, one rank): the launch also leaves the sum of squares of its block's results in norm_partial[block]
+// (fixed tree order), so that |s|^2 needs no pass of its own.
+template <bool NORM = false>
+__global__ __launch_bounds__(256) void rhs_gather_kernel(int node0, int node1, const int64_t *__restrict__ inc_ptr, int slot_stride,
                                   const double *__restrict__ fslot, const double *__restrict__ mxbar, int add_base,
-                                  const unsigned char *__restrict__ base_mask, double *__restrict__ y) {
+                                  const unsigned char *__restrict__ base_mask, double *__restrict__ y, double *__restrict__ norm_partial = nullptr) {
+    __shared__ double red[NORM ? 256 : 1];
     const int i = 3 * node0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * node1) return;
-    const int node = i / 3, c = i - 3 * node;
-    double acc = 0.0;
-    const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
-    if (slot_stride) {      // rank-major slots: lane i reads word i of every rank's array
-        const int deg = (int)(p1 - p0);
-        const double *f = fslot + i;
-        int r = 0;
+    const bool ok = i < 3 * node1;      // (no early return under NORM: every thread of the block takes part in the barriers below)
+    if (!NORM && !ok) return;
+    double out = 0.0;
+    if (ok) {
+        const int node = i / 3, c = i - 3 * node;
+        double acc = 0.0;
+        const int64_t p0 = inc_ptr[node], p1 = inc_ptr[node + 1];
+        if (slot_stride) {      // rank-major slots: lane i reads word i of every rank's array
+            const int deg = (int)(p1 - p0);
+            const double *f = fslot + i;
+            int r = 0;
 #if ADMM_RHS_UNROLL
-        for (; r + 8 <= deg; r += 8) {      // eight independent loads in flight; the sum keeps its order
-            double t[8];
+            for (; r + 8 <= deg; r += 8) {      // eight independent loads in flight; the sum keeps its order
+                double t[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = f[3 * (size_t)(r + q) * slot_stride];
+                for (int q = 0; q < 8; ++q) t[q] = f[3 * (size_t)(r + q) * slot_stride];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += t[q];
-        }
+                for (int q = 0; q < 8; ++q) acc += t[q];
+            }
 #endif
-        for (; r < deg; ++r) acc += f[3 * (size_t)r * slot_stride];
-    } else {
-        for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
+            for (; r < deg; ++r) acc += f[3 * (size_t)r * slot_stride];
+        } else {
+            for (int64_t p = p0; p < p1; ++p) acc += fslot[3 * (size_t)p + c];
+        }
+        const bool base = base_mask ? (base_mask[node] != 0) : (add_base != 0);
+        out = base ? (mxbar[i] + acc) : acc;
+        y[i] = out;
     }
-    const bool base = base_mask ? (base_mask[node] != 0) : (add_base != 0);
-    y[i] = base ? (mxbar[i] + acc) : acc;
+    if (NORM) {
+        red[threadIdx.x] = out * out;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+        if (threadIdx.x == 0) norm_partial[blockIdx.x] = red[0];
+    }
 }
 
 // ---- subtree sharding of the solve (one process per GPU): the exchange between a rank's own subtrees and the replicated

@@ -54,6 +54,7 @@ struct BatchDev {
     const double *kblend;  // [n]  stiffness * measure (blended kinds)
     const double *w2;      // [n]  weight^2
     double *u, *z;         // SoA [rows][n]
+    int keep_z;            // tet kernels: store z (see project_tet_kernel's epilogue)
     double *state;         // SoA [4][n]
     int *n_iters;          // [n]
     double *fslot;         // [total incidences][3], node-sorted (see rhs_gather_kernel)
@@ -258,7 +259,7 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
 #else
         b.state[(size_t)0 * n + e] = sa; b.state[(size_t)1 * n + e] = sb; b.state[(size_t)2 * n + e] = sc; b.state[(size_t)3 * n + e] = hs;
 #endif
-        b.n_iters[e] = it;
+        if (TRACK || b.keep_z) b.n_iters[e] = it;      // (an introspection output like z: admm_hip_read_local's n_iters)
     } else {
         const double lmin = (KIND == 3) ? b.par[(size_t)1 * n + e] : 0.0, lmax = (KIND == 3) ? b.par[(size_t)2 * n + e] : 0.0;
         const Mat3 p = project_tet_p<KIND == 3>(F, lmin, lmax);
@@ -283,7 +284,10 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         dz.m00 = z.m00 - zp.m00; dz.m10 = z.m10 - zp.m10; dz.m20 = z.m20 - zp.m20; dz.m01 = z.m01 - zp.m01; dz.m11 = z.m11 - zp.m11; dz.m21 = z.m21 - zp.m21;
         dz.m02 = z.m02 - zp.m02; dz.m12 = z.m12 - zp.m12; dz.m22 = z.m22 - zp.m22;
     }
-#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (TRACK) { const double du = un - u.mm; r2 += du * du; } st_stream(&b.u[(size_t)row * n + e], un); st_stream(&b.z[(size_t)row * n + e], z.mm); }
+    // z is an output nobody reads back in a plain frame (every project() overwrites it from Dx + u): stored only when somebody
+    // asked (keep_z: tracking, the parity entry points, admm_hip_keep_z) -- 72 B per tet and iteration less otherwise
+    const bool keep_z = TRACK || b.keep_z;
+#define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (TRACK) { const double du = un - u.mm; r2 += du * du; } st_stream(&b.u[(size_t)row * n + e], un); if (keep_z) st_stream(&b.z[(size_t)row * n + e], z.mm); }
     ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
 #undef ADMM_UZ
     const double s = b.w2h2[e];
@@ -310,28 +314,30 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         // goes to its place in the block's LDS staging (corners sorted by node, then lane, then corner: pos4), then one lane per
         // distinct node sums the node's run front to back (fixed order: deterministic) and writes ONE 24-byte slot -- 1.1 KB of slot
         // traffic per block instead of 6 KB of scattered 8-byte stores, and a gather that reads ~6 slots per node instead of ~24.
-        __shared__ double stage[3 * 256];
+        __shared__ double stage[(TRACK ? 6 : 3) * 256];
         const unsigned int p4 = b.pos4[e];
         const unsigned long long act = __ballot(1);
         const int nact = __popcll(act), lane = threadIdx.x & 63;
         const int q0 = b.bn_ptr[blk], q1 = b.bn_ptr[blk + 1];
-        auto reduce_to = [&](const double (&v)[12], double *slots) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int p = (p4 >> (8 * c)) & 255;
-                stage[p] = v[3 * c]; stage[256 + p] = v[3 * c + 1]; stage[512 + p] = v[3 * c + 2];
+        for (int c = 0; c < 4; ++c) {
+            const int p = (p4 >> (8 * c)) & 255;
+            stage[p] = f[3 * c]; stage[256 + p] = f[3 * c + 1]; stage[512 + p] = f[3 * c + 2];
+            if (TRACK) { stage[768 + p] = g[3 * c]; stage[1024 + p] = g[3 * c + 1]; stage[1280 + p] = g[3 * c + 2]; }      // the s shares ride along in the same pass
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave per block: its own LDS writes are done, no barrier needed
+        for (int i = q0 + lane; i < q1; i += nact) {
+            const int k1 = b.bn_end[i], k0 = (i == q0) ? 0 : (int)b.bn_end[i - 1];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+            for (int k = k0; k < k1; ++k) {
+                a0 += stage[k]; a1 += stage[256 + k]; a2 += stage[512 + k];
+                if (TRACK) { g0 += stage[768 + k]; g1 += stage[1024 + k]; g2 += stage[1280 + k]; }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave per block: its own LDS writes are done, no barrier needed
-            for (int i = q0 + lane; i < q1; i += nact) {
-                const int k1 = b.bn_end[i], k0 = (i == q0) ? 0 : (int)b.bn_end[i - 1];
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-                for (int k = k0; k < k1; ++k) { a0 += stage[k]; a1 += stage[256 + k]; a2 += stage[512 + k]; }
-                double *o = slots + 3 * (size_t)b.bn_dst[i];
-                o[0] = a0; o[1] = a1; o[2] = a2;
-            }
-        };
-        reduce_to(f, b.fslot);
-        if (TRACK) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); reduce_to(g, b.res_slots); }
+            const size_t d = 3 * (size_t)b.bn_dst[i];
+            double *o = b.fslot + d;
+            o[0] = a0; o[1] = a1; o[2] = a2;
+            if (TRACK) { double *r = b.res_slots + d; r[0] = g0; r[1] = g1; r[2] = g2; }
+        }
     } else {
         const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
         double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;

@@ -137,6 +137,7 @@ public:
         m_v.setZero();
         if (admm_hip_create(&gpu, device_id) != ADMM_OK) { std::cerr << "\n**Solver Error: no usable HIP device " << device_id << " (the built-in forces have no CPU path)" << std::endl; gpu = nullptr; return false; }
         if (!check(admm_hip_set_timestep(gpu, settings.timestep_s))) return false;
+        if (!check(admm_hip_keep_z(gpu, 0))) return false;       // curr_z is not part of the class's public surface: no need to store it every iteration
         if (!setup_shard()) return false;
         if (!check(admm_hip_add_nodes(gpu, dof / 3, m_x.data(), m_masses.data(), nullptr))) return false;
         // Force::initialize of the user-written forces (System.cpp:117-119); the built-in ones compute their rest data in the library

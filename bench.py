@@ -37,8 +37,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured achievable)
 VALU_ISSUE_SLOTS_PER_S = 1024 * 2.4e9 / 4.0   # 256 CUs x 4 SIMDs at 2.4 GHz; one wave-wide VALU instruction occupies a SIMD for 4 cycles (fp64 FMA: more)
-RHS_BYTES_PER_TET, RHS_BYTES_PER_NODE = 96.0, 48.0   # rhs_gather_kernel: 4 slots x 24 B per tet + M x_bar read and b written per node
-LOCAL_BYTES_PER_TET = 472.0    # read 296 B + write 176 B per tet per ADMM iteration
+RHS_BYTES_PER_NODE = 48.0      # rhs_gather_kernel: M x_bar read and b written per node (+ the slots, counted from info.rhs_slots)
+# SURVEY.md section 8(d) prices the tet kernel at 472 B per tet and ADMM iteration (read 296 B + write 176 B).  Since round 3 a
+# production frame no longer stores z (72 B: nobody reads it back, admm_hip_keep_z) -- the honest algorithmic figure is 400 B.
+LOCAL_BYTES_PER_TET = 400.0
 ADMM_ITERS = 20
 
 
@@ -129,6 +131,7 @@ def other_configs(pkg, torch, steps):
     res = {}
 
     def measure(s, n_el, label):
+        s.keep_z(False)
         s.initialize()
         for _ in range(3):          # three warm-up frames (graph capture, cost-ordered launch, clocks), then the median of three timed runs
             s.step(ADMM_ITERS)
@@ -340,6 +343,7 @@ def main():
             ranks_seen = int(round(float(ones.item())))
         if ranks_seen != (world if not fake_dist else 1):      # an N-rank launch whose collective joins fewer ranks is not an N-GPU run
             raise SystemExit("bench.py: rank %d: the all-reduce path joins %d ranks, expected %d" % (rank, ranks_seen, world))
+    s.keep_z(False)      # production frames: the tet batches' z is never read back (what host/admm/System.hpp does too)
     s.initialize()
     t_init = time.time() - t0
     info = s.info()
@@ -438,11 +442,12 @@ def main():
         print("bench: PMC summary %s unusable: %r" % (pmc_file, e), file=sys.stderr)
     # the whole ADMM iteration against the HBM roof: algorithmic bytes of every kernel of one iteration over the iteration's time
     it_s = phase["total_ms"] * 1e-3 / iters_total
-    it_bytes = (LOCAL_BYTES_PER_TET + RHS_BYTES_PER_TET) * (n_tets / world) + RHS_BYTES_PER_NODE * info["n_nodes"] + 2.0 * panel_bytes
+    # (the RHS slots: written once by the local kernels, read once by the gather -- one per (64-tet block, node) since the block-level pre-reduction)
+    it_bytes = LOCAL_BYTES_PER_TET * (n_tets / world) + 2.0 * 24.0 * info.get("rhs_slots", 4 * n_tets) + RHS_BYTES_PER_NODE * info["n_nodes"] + 2.0 * panel_bytes
     iteration = None
     if a.config == "bar" and not (world > 1 and a.shard == "subtree"):
         iteration = {"bytes": it_bytes, "ms": it_s * 1e3, "GB/s": it_bytes / it_s / 1e9 if it_s > 0 else 0.0, "frac": (it_bytes / it_s / 1e9 / HBM_PEAK_GBS) if it_s > 0 else 0.0,
-                     "what": "tet kernel 472 B/tet + RHS gather 96 B/tet + 48 B/node + the factor panels and vectors once per sweep, over the mean ADMM iteration (HIP events, total_ms)"}
+                     "what": "tet kernel 400 B/tet + the RHS slots written and read once (24 B each) + 48 B/node + the factor panels and vectors once per sweep, over the mean ADMM iteration (HIP events, total_ms)"}
     roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
             "valu_frac": (valu or {}).get("valu_frac"),

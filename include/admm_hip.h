@@ -217,6 +217,11 @@ int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v);
  * protected System::curr_u / curr_z (System.hpp:98-99) and
  * HyperElasticTet::last_prox_result (TetForce.hpp:146).                      */
 int admm_hip_read_local(admm_hip_ctx *ctx, int batch, double *u, double *z, double *state, int32_t *n_iters);
+/* z of the tet batches is an output nobody reads back in a plain frame -- every project() overwrites it from Dx + u (the
+ * reference's curr_z is a protected member, System.hpp:98-99).  admm_hip_keep_z(ctx, 0) stops admm_hip_step from storing
+ * it (72 bytes per tet and ADMM iteration less; what host/admm/System.hpp and bench.py do); read_local's z is then the
+ * value of the last call that kept it.  Default: kept.  The parity entry points below and residual tracking always keep it. */
+int admm_hip_keep_z(admm_hip_ctx *ctx, int on);
 int admm_hip_write_local(admm_hip_ctx *ctx, int batch, const double *u, const double *state);
 /* rest data computed by Force::initialize: weight [n], rest [n][12] (tets: B 4x3
  * col-major; tris: B 3x2 in the first 6; bend: alpha[4]; spring: rest length),
@@ -262,6 +267,7 @@ typedef struct admm_hip_info {
     int32_t rank, world, device_id, host_threads;
     int32_t dense_solve;      /* 1: small system, solved as x = A_s^-1 b with the explicit inverse (see admm_hip_finalize) */
     int32_t device_factor;    /* 1: the numeric factorization ran on the GPU (csrc/factor_dev.hpp), 0: on the host */
+    int64_t rhs_slots;        /* 24-byte slots the local kernels write and the RHS gather reads per ADMM iteration (this rank) */
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
 
@@ -282,7 +288,7 @@ int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t);
  *     r = W (Dx - z)            primal residual, with the Dx the local step used
  *     s = D^T W^T W (z - z_prev) dual residual
  * With tracking on, every ADMM iteration of admm_hip_step also computes |r|_2 and |s|_2 (extra
- * passes over u/z: about +20 % per iteration at 1M tets; off by default = the reference's loop).
+ * work inside the tet / anchor kernels plus one more gather: about +9 % per iteration at 1M tets; off by default = the reference's loop).
  * admm_hip_get_residuals copies the norms of the last step; *n_iters = ADMM iterations that step ran.
  * admm_hip_set_tolerance(eps_r, eps_s, check_every): with eps_r > 0 the ADMM loop of a step ends as
  * soon as |r| <= eps_r and |s| <= eps_s, tested every `check_every` iterations (each test is one
