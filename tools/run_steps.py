@@ -7,6 +7,7 @@ from __graft_entry__ import load_package
 pkg = load_package()
 nx, ny, nz, frames = (int(v) for v in sys.argv[1:5])
 s = pkg.make_bar_system(nx, ny, nz, device_id=0)
+s.keep_z(False)      # production frames, like bench.py
 s.initialize()
 for _ in range(frames):
     s.step(20)
