@@ -256,6 +256,44 @@ def test_backward_kernel_shapes(pkg, monkeypatch, nw, cw2, small_nw):
         assert np.array_equal(x, s.solve_only(b))
 
 
+def test_prereduced_rhs_and_unkept_z(pkg, monkeypatch):
+    """Round-3 changes of the tet kernels' epilogue that must not change what is computed:
+    * block-level pre-reduction of the RHS shares (one slot per (64-tet block, node), summed in LDS in a fixed order) against
+      one slot per corner (ADMM_HIP_PRERED=0): the local step's own outputs u, z, state are bitwise the same, the assembled
+      right-hand side differs only in the order of its per-node sums (one iteration: rounding level), runs are bitwise reproducible;
+    * admm_hip_keep_z(0) -- production frames do not store the tets' z, nobody reads it back (reference: curr_z is overwritten by
+      every project(), System.cpp:57-58) -- leaves x, v, u and the warm-start state bitwise untouched; the parity entry point
+      (local_step_only) still delivers z."""
+    dims = (5, 4, 11)            # 1320 tets: 20 full blocks + one of 40 tets
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+
+    def make(kind="TET_NH"):
+        s = pkg.make_bar_system(*dims, kind=KIND[kind], device_id=0); s.initialize(); return s
+    a = make(); a2 = make()
+    monkeypatch.setenv("ADMM_HIP_PRERED", "0")
+    b = make()
+    monkeypatch.delenv("ADMM_HIP_PRERED")
+    x, _ = pkg.meshgen.bar(*dims)
+    xs = x.ravel() * (1.0 + 0.01 * np.sin(np.arange(x.size)))
+    a.local_step_only(xs); a2.local_step_only(xs); b.local_step_only(xs)
+    la, lb = a.read_local(0), b.read_local(0)
+    for k in ("u", "z", "state"):
+        assert np.array_equal(la[k], lb[k]), k
+    a.step(1); a2.step(1); b.step(1)
+    assert np.array_equal(a.m_x, a2.m_x)
+    assert np.abs(a.m_x - b.m_x).max() < 1e-12
+    # z not kept: same trajectory, same u / state; z is whatever the last keeping call left
+    c = make(); c.keep_z(False)
+    d = make()
+    for _ in range(2):
+        c.step(5); d.step(5)
+    assert np.array_equal(c.m_x, d.m_x) and np.array_equal(c.m_v, d.m_v)
+    lc, ld = c.read_local(0), d.read_local(0)
+    assert np.array_equal(lc["u"], ld["u"]) and np.array_equal(lc["state"], ld["state"])
+    c.local_step_only(xs); d.local_step_only(xs)
+    assert np.array_equal(c.read_local(0)["z"], d.read_local(0)["z"])
+
+
 @pytest.mark.parametrize("groups,scene", [("2", "bar"), ("3", "bar"), ("2", "mixed")])
 def test_pipelined_groups_bitwise_equal_serial_launch(pkg, monkeypatch, groups, scene):
     """ADMM_HIP_PIPE=G (opt-in experiment): elements and elimination subtrees in G groups, every group's chain
