@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Probe (GPU box): the class API's frame boundary (upload_state + step + download_state on page-locked vectors) against the resident
+loop at the 1M-tet bar, with everything on the solver's stream.  (Round 3 tried v on a second transfer stream -- a second DMA engine beside x: the four
+transfers alone 0.385 instead of 0.403 ms per frame, i.e. one engine already moves ~43 GB/s of the link's 64, but around the step the
+frame was SLOWER (+3.5-4 % against +1.3-1.6 % over the resident loop): the extra stream's events sit in the prologue's way.  Not kept;
+the ADMM_HIP_XFER2 knob this script sets no longer exists.)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+pkg = load_package()
+sims = {}
+for name, env in (("two streams", "1"), ("one stream", "0")):
+    os.environ["ADMM_HIP_XFER2"] = env
+    s = pkg.make_bar_system(32, 32, 163); s.keep_z(False); s.initialize()
+    s.step(20); s.sync()
+    hx = s.m_x.copy(); hv = s.m_v.copy(); s.pin_host(hx); s.pin_host(hv)
+    sims[name] = (s, hx, hv)
+for r in range(3):
+    for name, (s, hx, hv) in sims.items():
+        t = time.perf_counter()
+        for _ in range(6): s.upload_state(hx, hv); s.step(20); s.download_state(hx, hv)
+        tc = (time.perf_counter() - t) / 6
+        t = time.perf_counter()
+        for _ in range(6): s.step(20)
+        s.sync(); tr = (time.perf_counter() - t) / 6
+        t = time.perf_counter()
+        for _ in range(6): s.upload_state(hx, hv); s.download_state(hx, hv)
+        tx = (time.perf_counter() - t) / 6
+        print("round %d  %-12s class API %.3f ms/frame, resident %.3f: +%.2f %%; the four transfers alone %.3f ms" % (r, name, 1e3 * tc, 1e3 * tr, 100 * (tc / tr - 1), 1e3 * tx), flush=True)
