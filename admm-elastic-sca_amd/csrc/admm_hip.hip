@@ -2072,6 +2072,7 @@ static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, v
     hipStream_t st = (hipStream_t)hip_stream;
     if (!ctx->host_allreduce) return 1;
     if ((size_t)count > ctx->h_comm_cap) {
+        (void)hipStreamSynchronize(st);      // the previous call's host-to-device copy may still be reading the old staging buffer
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
@@ -2507,9 +2508,13 @@ int admm_hip_read_rest(admm_hip_ctx *ctx, int batch, double *weight, double *res
 int admm_hip_keep_z(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     if (getenv("ADMM_HIP_KEEP_Z")) return ADMM_OK;      // the environment decides
-    if (ctx->keep_z_user != (on != 0) && ctx->iter_exec) {      // the captured iteration carries the flag in its kernel arguments
-        (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr;
+    if (ctx->keep_z_user != (on != 0)) {      // captured iterations carry the flag in their kernel arguments: capture again
+        if (ctx->iter_exec) { (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr; }
         if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
+        for (int q = 0; q < 3; ++q) {
+            if (ctx->pipe_exec[q]) { (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; }
+            if (ctx->pipe_graph_h[q]) { (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }
+        }
     }
     ctx->keep_z_user = on != 0;
     return ADMM_OK;

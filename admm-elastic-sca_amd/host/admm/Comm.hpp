@@ -91,7 +91,7 @@ public:
         }
         void *p = ::mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         ::close(fd);
-        if (p == MAP_FAILED) return false;
+        if (p == MAP_FAILED) { if (rank == 0) ::shm_unlink(name.c_str()); return false; }
         hdr_ = static_cast<Header *>(p);
         data_ = reinterpret_cast<double *>(static_cast<char *>(p) + sizeof(Header));
         if (rank == 0) {
