@@ -107,6 +107,20 @@ def test_scene_through_class_api(pkg, tmp_path, typ):
     assert np.abs(cp_final - np.array(list(o.force(h).pos))).max() < 2e-4
 
 
+def test_shard_from_env(pkg):
+    """System::shard.from_env() reads what torchrun / Open MPI / Slurm export (the C++ host's way to one process per GPU)."""
+    exe = compile_cpp("shard_env", pkg)
+    clean = {k: v for k, v in os.environ.items() if not any(k.startswith(p) for p in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_", "SLURM_", "MASTER_", "ADMM_HIP_RCCL"))}
+
+    def run(**env):
+        return subprocess.run([exe], capture_output=True, text=True, env=dict(clean, **env), timeout=60).stdout.strip()
+    assert run() == "local -1 rank 0 world 1 file"
+    out = run(RANK="3", WORLD_SIZE="8", LOCAL_RANK="3", MASTER_PORT="29511")
+    assert out.startswith("local 3 rank 3 world 8 file /tmp/admm_hip_rccl_id.") and out.endswith(".29511")
+    assert run(OMPI_COMM_WORLD_RANK="5", OMPI_COMM_WORLD_SIZE="16", OMPI_COMM_WORLD_LOCAL_RANK="1", ADMM_HIP_RCCL_ID_FILE="/shared/job7.id") == "local 1 rank 5 world 16 file /shared/job7.id"
+    assert run(SLURM_PROCID="2", SLURM_NTASKS="4", SLURM_LOCALID="2", SLURM_JOB_ID="991").endswith(".991")
+
+
 def test_comm_helpers_on_the_cpu(pkg, tmp_path):
     """host/admm/Comm.hpp without a GPU: the shared-memory all-reduce between three processes (every rank gets the sum added
     in rank order, bit for bit, also when the buffer needs several rounds through the segment) and the rendezvous file that
