@@ -3,15 +3,14 @@
 loop at the 1M-tet bar, with everything on the solver's stream.  (Round 3 tried v on a second transfer stream -- a second DMA engine beside x: the four
 transfers alone 0.385 instead of 0.403 ms per frame, i.e. one engine already moves ~43 GB/s of the link's 64, but around the step the
 frame was SLOWER (+3.5-4 % against +1.3-1.6 % over the resident loop): the extra stream's events sit in the prologue's way.  Not kept;
-the ADMM_HIP_XFER2 knob this script sets no longer exists.)"""
+that variant is not in the library any more.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 sims = {}
-for name, env in (("two streams", "1"), ("one stream", "0")):
-    os.environ["ADMM_HIP_XFER2"] = env
+for name in ("class API",):
     s = pkg.make_bar_system(32, 32, 163); s.keep_z(False); s.initialize()
     s.step(20); s.sync()
     hx = s.m_x.copy(); hv = s.m_v.copy(); s.pin_host(hx); s.pin_host(hv)
