@@ -746,6 +746,11 @@ constexpr int ROOT_KCHUNK = 2048;
 #define ADMM_ROOT_ROWS 16         // rows (= waves) per block of root_product_kernel: one staging of t per block (4 / 8 / 16 rows: 37 / 22 / 20 us at k = 3301)
 #endif
 constexpr int ROOT_ROWS = ADMM_ROOT_ROWS;
+// ADMM_ROOT_NT: the root's explicit inverse is read ONCE per ADMM iteration (it serves both sweeps in one product): loaded
+// non-temporally it does not take the Infinity Cache away from the top levels' panels, which the backward sweep re-reads next.
+#ifndef ADMM_ROOT_NT
+#define ADMM_ROOT_NT 1
+#endif
 __global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X) {
     __shared__ double ts[ROOT_KCHUNK * 3 + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -766,7 +771,10 @@ __global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int
         for (; j + 448 < kc2; j += 512) {
             double2 a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = rp2[j + 64 * u];
+            for (int u = 0; u < 8; ++u) {
+                if (ADMM_ROOT_NT) { typedef double d2_t __attribute__((ext_vector_type(2))); const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(&rp2[j + 64 * u])); a[u].x = t2.x; a[u].y = t2.y; }
+                else a[u] = rp2[j + 64 * u];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const double *t = &ts[6 * (j + 64 * u)];
@@ -784,7 +792,7 @@ __global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int
         for (; j + 448 < kc; j += 512) {
             double a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = rp[c0 + j + 64 * u];
+            for (int u = 0; u < 8; ++u) a[u] = ADMM_ROOT_NT ? __builtin_nontemporal_load(&rp[c0 + j + 64 * u]) : rp[c0 + j + 64 * u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const double *t = &ts[3 * (j + 64 * u)]; v[0] += a[u] * t[0]; v[1] += a[u] * t[1]; v[2] += a[u] * t[2]; }
         }
