@@ -490,10 +490,15 @@ ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &
         else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
-    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
-    else {
-        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
+    // the interval update (:293-300) as selects on VALUES with one unconditional store per reference.  Written with branches
+    // ("if (fp > fx) { fy = fp; ... } else { ...; fx = fp; ... }") hipcc sinks the two stores of fp into ONE store through a selected
+    // POINTER, which keeps fx / fy / dx / dy of the caller in scratch memory: a store -> load round trip through the memory pipe on the
+    // dependent chain of every line-search evaluation (15 scratch instructions per evaluation in the round-2 kernel).
+    {
+        const bool up = fp > fx, neg = sgnd < 0.0;
+        const double nsty = up ? stp : (neg ? stx : sty), nfy = up ? fp : (neg ? fx : fy), ndy = up ? dp : (neg ? dx : dy);
+        const double nstx = up ? stx : stp, nfx = up ? fx : fp, ndx = up ? dx : dp;
+        sty = nsty; fy = nfy; dy = ndy; stx = nstx; fx = nfx; dx = ndx;
     }
     stpf = smin(stpmax, stpf);
     stpf = smax(stpmin, stpf);
@@ -565,26 +570,29 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         if (info != 0) return stp;
         if (stage1 & (f <= ftest1) & (dg >= smin(ftol, gtol) * dginit)) stage1 = false;
         // modified function in stage 1 (:118-138): one cstep call on selected operands (see mt_cstep)
+        // (fx, fy, dgx, dgy are modified IN PLACE around the call -- the reference's fxm = fx - stx * dgtest ... fx = fxm + stx * dgtest on
+        // the same operands -- instead of going through four copies handed to mt_cstep by reference: hipcc kept those copies in
+        // scratch memory, a store -> load round trip through the memory pipe on the dependent chain of every evaluation)
         const bool modified = stage1 & (f <= fx) & (f > ftest1);
-        double cf = f, cdg = dg, cfx = fx, cfy = fy, cdgx = dgx, cdgy = dgy;
+        double cf = f, cdg = dg;
         if (modified) {
 #ifdef ADMM_CSTEP_STATS
             ADMM_CSTEP_STATS[0]++;
 #endif
             cf = f - stp * dgtest;
-            cfx = fx - stx * dgtest;
-            cfy = fy - sty * dgtest;
+            fx = fx - stx * dgtest;
+            fy = fy - sty * dgtest;
             cdg = dg - dgtest;
-            cdgx = dgx - dgtest;
-            cdgy = dgy - dgtest;
+            dgx = dgx - dgtest;
+            dgy = dgy - dgtest;
         }
-        mt_cstep(stx, cfx, cdgx, sty, cfy, cdgy, stp, cf, cdg, brackt, stmin, stmax, infoc);
+        mt_cstep(stx, fx, dgx, sty, fy, dgy, stp, cf, cdg, brackt, stmin, stmax, infoc);
         if (modified) {
-            fx = cfx + stx * dgtest;
-            fy = cfy + sty * dgtest;
-            dgx = cdgx + dgtest;
-            dgy = cdgy + dgtest;
-        } else { fx = cfx; fy = cfy; dgx = cdgx; dgy = cdgy; }
+            fx = fx + stx * dgtest;
+            fy = fy + sty * dgtest;
+            dgx = dgx + dgtest;
+            dgy = dgy + dgtest;
+        }
         if (brackt) {
             if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
             width1 = width;
