@@ -38,9 +38,6 @@ namespace admm_dev {
 #define ADMM_LOCAL_BLOCK 64
 #endif
 constexpr int LOCAL_BLOCK = ADMM_LOCAL_BLOCK;
-#ifndef ADMM_EPI_PREFETCH
-#define ADMM_EPI_PREFETCH 1   // the tet kernels request their epilogue's inputs ahead of the recomposition (see project_tet_kernel)
-#endif
 #ifndef ADMM_TET_WAVES
 #define ADMM_TET_WAVES 2   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
 #endif
@@ -237,21 +234,6 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
     tet_load(b, x, e, n, B, Dx, u);
     F = mat_add(Dx, u);
     ADMM_PROF_TIME(0);
-    // What the epilogue reads -- the element's dt^2 w^2, its four staging positions, this lane's node entry of the block -- is
-    // requested between the minimisation and the recomposition (project_hyper's `mid` hook), where the prox's registers are free and
-    // ~2 us of arithmetic lie ahead; the epilogue's three dependent latencies then cost nothing.  Worth 2-3 us since the line-search
-    // loop lost its scratch round trips (before that: nothing, NOTES section A); 4 spilled VGPRs outside the loops.
-    double s_w = 0.0; unsigned int p4 = 0; int q0 = 0, q1 = 0, nk0 = 0, nk1 = 0, ndst = 0; bool pre = false;
-    auto epi_prefetch = [&]() {
-        pre = true;
-        s_w = b.w2h2[e];
-        if (b.pos4) {
-            p4 = b.pos4[e];
-            q0 = b.bn_ptr[blk]; q1 = b.bn_ptr[blk + 1];
-            const int i = q0 + (int)(threadIdx.x & 63);
-            if (i < q1) { nk1 = b.bn_end[i]; nk0 = (i == q0) ? 0 : (int)b.bn_end[i - 1]; ndst = b.bn_dst[i]; }
-        }
-    };
     if (KIND <= 1) {
 #if ADMM_LOCAL_NT >= 2
         const double mu = ld_stream(&b.par[(size_t)0 * n + e]), lambda = ld_stream(&b.par[(size_t)1 * n + e]);
@@ -263,17 +245,15 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         double sa = b.state[(size_t)0 * n + e], sb = b.state[(size_t)1 * n + e], sc = b.state[(size_t)2 * n + e], hs = b.state[(size_t)3 * n + e];
 #endif
         int it = 0;
-        auto mid = [&]() {
-#if ADMM_EPI_PREFETCH
-            epi_prefetch();
-#endif
-            if (TRACK) {
+        if (TRACK) {
+            auto load_zprev = [&]() {
 #define ADMM_ZP(mm, row) zp.mm = ld_stream(&b.z[(size_t)row * n + e]);
                 ADMM_ZP(m00, 0) ADMM_ZP(m10, 1) ADMM_ZP(m20, 2) ADMM_ZP(m01, 3) ADMM_ZP(m11, 4) ADMM_ZP(m21, 5) ADMM_ZP(m02, 6) ADMM_ZP(m12, 7) ADMM_ZP(m22, 8)
 #undef ADMM_ZP
-            }
-        };
-        z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it, mid);
+            };
+            z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it, load_zprev);
+        } else
+        z = project_hyper<KIND, M>(F, mu, lambda, maxIter, sa, sb, sc, hs, it);
 #if ADMM_LOCAL_NT >= 2
         st_stream(&b.state[(size_t)0 * n + e], sa); st_stream(&b.state[(size_t)1 * n + e], sb); st_stream(&b.state[(size_t)2 * n + e], sc); st_stream(&b.state[(size_t)3 * n + e], hs);
 #else
@@ -310,8 +290,7 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
 #define ADMM_UZ(mm, row) { const double un = u.mm + (Dx.mm - z.mm); q.mm = z.mm - un; if (TRACK) { const double du = un - u.mm; r2 += du * du; } st_stream(&b.u[(size_t)row * n + e], un); if (keep_z) st_stream(&b.z[(size_t)row * n + e], z.mm); }
     ADMM_UZ(m00, 0) ADMM_UZ(m10, 1) ADMM_UZ(m20, 2) ADMM_UZ(m01, 3) ADMM_UZ(m11, 4) ADMM_UZ(m21, 5) ADMM_UZ(m02, 6) ADMM_UZ(m12, 7) ADMM_UZ(m22, 8)
 #undef ADMM_UZ
-    if (!pre) epi_prefetch();
-    const double s = s_w;
+    const double s = b.w2h2[e];
     // f_c[j] = s * sum_r B(c, r) q(j, r)
     double f[12];
 #pragma unroll
@@ -336,8 +315,10 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         // distinct node sums the node's run front to back (fixed order: deterministic) and writes ONE 24-byte slot -- 1.1 KB of slot
         // traffic per block instead of 6 KB of scattered 8-byte stores, and a gather that reads ~6 slots per node instead of ~24.
         __shared__ double stage[(TRACK ? 6 : 3) * 256];
+        const unsigned int p4 = b.pos4[e];
         const unsigned long long act = __ballot(1);
         const int nact = __popcll(act), lane = threadIdx.x & 63;
+        const int q0 = b.bn_ptr[blk], q1 = b.bn_ptr[blk + 1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int p = (p4 >> (8 * c)) & 255;
@@ -346,14 +327,13 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave per block: its own LDS writes are done, no barrier needed
         for (int i = q0 + lane; i < q1; i += nact) {
-            const bool first = i == q0 + lane;
-            const int k1 = first ? nk1 : (int)b.bn_end[i], k0 = first ? nk0 : (int)b.bn_end[i - 1];
+            const int k1 = b.bn_end[i], k0 = (i == q0) ? 0 : (int)b.bn_end[i - 1];
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
             for (int k = k0; k < k1; ++k) {
                 a0 += stage[k]; a1 += stage[256 + k]; a2 += stage[512 + k];
                 if (TRACK) { g0 += stage[768 + k]; g1 += stage[1024 + k]; g2 += stage[1280 + k]; }
             }
-            const size_t d = 3 * (size_t)(first ? ndst : b.bn_dst[i]);
+            const size_t d = 3 * (size_t)b.bn_dst[i];
             double *o = b.fslot + d;
             o[0] = a0; o[1] = a1; o[2] = a2;
             if (TRACK) { double *r = b.res_slots + d; r[0] = g0; r[1] = g1; r[2] = g2; }
