@@ -1811,6 +1811,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8 || v == 16) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
     if (const char *g = getenv("ADMM_HIP_TET_ORDER")) ctx->tet_order = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_TET_ORDER_MIN")) ctx->tet_order_min_blocks = atoi(g);
     if (const char *g = getenv("ADMM_HIP_FUSE_ANCHORS")) ctx->fuse_anchor_tail = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_FACTOR")) ctx->device_factor = std::string(g) != "host";
     if (const char *g = getenv("ADMM_HIP_BWD_CW2_MIN")) ctx->bwd_cw2_min_cols = atoi(g);
