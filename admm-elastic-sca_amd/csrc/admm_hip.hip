@@ -432,10 +432,12 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         const int64_t share = ctx->n_nodes / std::max(1, ctx->world);
         // (round 2, with this round's sweep kernels: per-rank forward + backward at 8 ranks, leaves 64 / 128 / 256 / 384 / 512:
         //  0.248 / 0.239 / 0.229 / 0.226 / 0.234 ms; at 4 ranks 64 / 128 / 256 / 384: 0.275 / 0.270 / 0.265 / 0.260; at 2 ranks 64 is best)
-        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (own_subtrees ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 25000 ? 256 : 64));
+        // (round 3, tools/probe/tree_policy_ab.py, us per ADMM iteration, leaf 64 without four-way nodes -> leaf 256 with them: 26.9k nodes
+        //  214 -> 181, 37.6k 253 -> 224, 47.5k 276 -> 254, 63.1k 311 -> 308; four-way nodes with leaves of 64: 63.1k 311 -> 301, 101.8k 443 -> 433)
+        const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (own_subtrees ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 55000 ? 256 : 64));
         // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
-        int merge_above = ctx->n_nodes < 25000 ? 1000 : 0;
+        int merge_above = ctx->n_nodes < 120000 ? 1000 : 0;
         if (const char *e = getenv("ADMM_HIP_MERGE")) merge_above = atoi(e);
         // large systems: only the top region merges (root = top separator + its two half-separators, solved as one dense product
         // with its explicit inverse): the two top levels of both sweeps -- ~20 us of latency each at 1M tets -- become one
