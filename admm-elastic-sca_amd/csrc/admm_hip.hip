@@ -437,7 +437,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         const int leaf = ctx->leaf_size > 0 ? ctx->leaf_size : (own_subtrees ? (share < 30000 ? 384 : (share < 60000 ? 256 : 64)) : (ctx->n_nodes < 55000 ? 256 : 64));
         // four-way tree nodes (a region's separator merged with its two half-separators) halve the level count again; worth 6-9 % on
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
-        int merge_above = ctx->n_nodes < 120000 ? 1000 : 0;
+        // (round 3: with every region above the leaf size a four-way node -- threshold 100 instead of 1000 -- 3.7k nodes 111 -> 100, 10k 146 -> 125,
+        //  37.6k 225 -> 210, 63.1k 303 -> 284, 101.8k 434 -> 419 us per iteration; at 178.6k any merging below the root costs 5 %: 673 -> 705-721)
+        int merge_above = ctx->n_nodes < 120000 ? 100 : 0;
         if (const char *e = getenv("ADMM_HIP_MERGE")) merge_above = atoi(e);
         // large systems: only the top region merges (root = top separator + its two half-separators, solved as one dense product
         // with its explicit inverse): the two top levels of both sweeps -- ~20 us of latency each at 1M tets -- become one
@@ -446,7 +448,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         if (const char *e = getenv("ADMM_HIP_MERGE_ROOT")) merge_root = atoi(e) != 0;
         int merge_small = ctx->merge_small;
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small);
+        int merge_depth = 2;
+        if (const char *e = getenv("ADMM_HIP_MERGE_DEPTH")) merge_depth = atoi(e);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth);
     }
     // numeric phase: on the device when there is one (device_factorize, from upload_factor / recompute_weights); the small-system
     // inverse and device-less contexts (CPU tests of the host factorization) factor here

@@ -120,6 +120,17 @@ struct ND {
     int merge = 0;
     bool merge_root = false;
     int merge_small = 0;      // regions of at most that many nodes (and more than a leaf) become four-way nodes as well: one level less near the leaves
+    int merge_depth = 2;      // bisection levels a merged node spans: 2 = four-way (three separators in one supernode), 3 = eight-way (seven)
+    // the part `H` of a merged node: its separators down to `d` more bisections join `cols`, what is left below becomes children
+    void gather(std::vector<int> &H, int d, int depth, std::vector<int> &kids, std::vector<int> &cols) {
+        if (H.empty()) return;
+        if ((int)H.size() <= leaf || d == 0) { kids.push_back(rec(H, depth)); return; }
+        std::vector<int> a, b, sh;
+        bisect(H, a, b, sh);
+        gather(a, d - 1, depth + 1, kids, cols);
+        gather(b, d - 1, depth + 1, kids, cols);
+        cols.insert(cols.end(), sh.begin(), sh.end());
+    }
     int rec(std::vector<int> &nodes, int depth = 0) {
         const int m = (int)nodes.size();
         if (m <= leaf) return emit(nodes);
@@ -131,15 +142,10 @@ struct ND {
         std::vector<int> kids;
         std::vector<int> cols;
         if (four) {
-            for (std::vector<int> *H : {&L, &R}) {
-                if (H->empty()) continue;
-                if ((int)H->size() <= leaf) { kids.push_back(rec(*H, depth + 1)); continue; }
-                std::vector<int> a, b, sh;
-                bisect(*H, a, b, sh);
-                if (!a.empty()) kids.push_back(rec(a, depth + 2));
-                if (!b.empty()) kids.push_back(rec(b, depth + 2));
-                cols.insert(cols.end(), sh.begin(), sh.end());
-            }
+            // the merged node's own root (merge_root alone) stays four-way: its explicit inverse is sized for three separators
+            const int d = ((merge > 0 && m > merge) || (merge_small > 0 && m <= merge_small)) ? merge_depth : 2;
+            gather(L, d - 1, depth + 1, kids, cols);
+            gather(R, d - 1, depth + 1, kids, cols);
         } else {
             if (!L.empty()) kids.push_back(rec(L, depth + 1));
             if (!R.empty()) kids.push_back(rec(R, depth + 1));
@@ -152,7 +158,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -166,7 +172,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small;
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth);
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
