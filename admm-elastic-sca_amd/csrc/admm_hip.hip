@@ -439,7 +439,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // mid-size scenes (10k / 18.8k nodes: 189 -> 173 / 228 -> 214 us per iteration), nothing at 178.6k nodes (tools/merge_sweep.py)
         // (round 3: with every region above the leaf size a four-way node -- threshold 100 instead of 1000 -- 3.7k nodes 111 -> 100, 10k 146 -> 125,
         //  37.6k 225 -> 210, 63.1k 303 -> 284, 101.8k 434 -> 419 us per iteration; at 178.6k any merging below the root costs 5 %: 673 -> 705-721)
-        int merge_above = ctx->n_nodes < 120000 ? 100 : 0;
+        //  the mixed scene of BASELINE configs[4], 140.6k nodes: 570 -> 540)
+        int merge_above = ctx->n_nodes < 160000 ? 100 : 0;
+        if (own_subtrees) merge_above = ctx->n_nodes < 25000 ? 1000 : 0;      // (subtree sharding: not re-measured this round, the round-2 rule stands)
         if (const char *e = getenv("ADMM_HIP_MERGE")) merge_above = atoi(e);
         // large systems: only the top region merges (root = top separator + its two half-separators, solved as one dense product
         // with its explicit inverse): the two top levels of both sweeps -- ~20 us of latency each at 1M tets -- become one

@@ -7,7 +7,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from __graft_entry__ import load_package
 pkg = load_package()
 scenes = (((13, 13, 50), "TET_STVK"), ((10, 10, 30), "TET_NH"), ((20, 20, 60), "TET_NH"), ((24, 24, 100), "TET_NH"),
-          ((22, 22, 70), "TET_NH"), ((24, 24, 75), "TET_NH"), ((28, 28, 120), "TET_NH"), ((32, 32, 163), "TET_NH"))
+          ((22, 22, 70), "TET_NH"), ((24, 24, 75), "TET_NH"), ((28, 28, 120), "TET_NH"), ((32, 32, 163), "TET_NH"), ((26, 26, 123, 158, 158), "MIXED"))
 if os.environ.get("WALK_AB_SCENES"): scenes = tuple(scenes[int(i)] for i in os.environ["WALK_AB_SCENES"].split(","))
 variants = [("off", {"ADMM_HIP_WALK": "0"}), ("on", {"ADMM_HIP_WALK": "-1"})]
 for extra in sys.argv[1:]:
@@ -18,7 +18,9 @@ for dims, kind in scenes:
     for name, env in variants:
         for k in keys: os.environ.pop(k, None)
         os.environ.update(env)
-        s = pkg.make_bar_system(*dims, kind=pkg.KIND[kind]); s.keep_z(False); s.initialize()
+        if kind == "MIXED": s, _ = pkg.make_mixed_system(*dims)      # configs[4]: NH + StVK tets, cloth triangles, hinges, anchors
+        else: s = pkg.make_bar_system(*dims, kind=pkg.KIND[kind])
+        s.keep_z(False); s.initialize()
         inf = s.info()
         n = inf["n_nodes"]
         rng = np.random.default_rng(1)
