@@ -448,7 +448,12 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // HBM-rate product of k^2 doubles (3335^2 x 8 B = 89 MB at the 1M-tet bar)
         bool merge_root = merge_above == 0 && ctx->root_inverse;
         if (const char *e = getenv("ADMM_HIP_MERGE_ROOT")) merge_root = atoi(e) != 0;
+        // Subtree sharding: a rank's own subtrees are mid-size systems (22k nodes each at 8 ranks of the 178.6k-node bar) whose levels are
+        // latency-bound, the replicated top is not: regions of up to 4/3 of a rank's share become four-way nodes, the top keeps its tree.
+        // Per-rank forward + backward (tools/fake_world_policy.sh, no-op all-reduce): 8 ranks 0.198 -> 0.173 ms (thresholds 20k / 30k / 40k /
+        // 60k: 0.181 / 0.173 / 0.173 / 0.234), 4 ranks 0.247 -> 0.220 (30k: 0.225, 60k: 0.220), 2 ranks 0.299 -> 0.281 (60k / 120k alike).
         int merge_small = ctx->merge_small;
+        if (own_subtrees && merge_small == 0 && share >= 4096) merge_small = (int)std::min<int64_t>(share * 4 / 3, 2000000000);      // (tiny shares: a merged node that moves to the top would be a large part of the system)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
         int merge_depth = 2;
         if (const char *e = getenv("ADMM_HIP_MERGE_DEPTH")) merge_depth = atoi(e);

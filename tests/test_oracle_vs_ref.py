@@ -168,7 +168,8 @@ def test_port_speed_within_20_percent_of_reference(pkg):
     dims = (16, 16, 65)
     x, t = pkg.meshgen.bar(*dims)
     m = pkg.meshgen.lumped_tet_mass(x, t, 1000.0)
-    ms = {}
+    # both systems alive, the same frames timed in alternation (whatever else loads this machine hits both), median of the per-frame ratios
+    sims = {}
     for name, cls in (("port", Oracle), ("reference", Ref)):
         s = cls(); s.settings(0.04, 20)
         s.add_nodes(x.ravel(), np.repeat(m, 3))
@@ -177,7 +178,10 @@ def test_port_speed_within_20_percent_of_reference(pkg):
         s.add_gravity([0, -9.8, 0])
         assert s.initialize()
         s.time_steps(1)
-        ms[name] = 1e3 * min(s.time_steps(1), s.time_steps(1)) / 20
-        del s
-    ratio = ms["port"] / ms["reference"]
+        sims[name] = s
+    ms = {"port": [], "reference": []}
+    for _ in range(4):
+        for name in ("port", "reference"):
+            ms[name].append(1e3 * sims[name].time_steps(1) / 20)
+    ratio = float(np.median(np.array(ms["port"]) / np.array(ms["reference"])))
     assert 0.8 <= ratio <= 1.2, ms
