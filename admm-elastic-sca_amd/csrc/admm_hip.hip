@@ -180,6 +180,9 @@ struct admm_hip_ctx {
     // host's launch work matters; at 1M tets the GPU is the limit and a replay is 0.5-2 % SLOWER than the same launches issued
     // eagerly (0.780 vs 0.766-0.775 ms per iteration, tools/graph_vs_eager.py).  ADMM_HIP_GRAPH=1 forces it, 0 disables it.
     bool graph_enabled = true, graph_forced = false; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
+    // the whole ADMM loop of a frame as ONE graph (one launch per frame instead of one per iteration: the ~5-9 us between two graph
+    // launches are 5-15 % of an iteration on small and mid-size scenes); captured for the iteration count of the call, again when it changes
+    bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0;
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
     // instead of a second round of workgroups for the few that did not fit (1M-tet bar: levels 3, 4, 6, 7 with 8.6-13.7 k columns:
@@ -284,9 +287,17 @@ template <class T> int upload(admm_hip_ctx *ctx, T **p, const std::vector<T> &h)
 }
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-void free_device(admm_hip_ctx *ctx) {
+// captured iterations carry device addresses and flags in their kernel arguments: whatever changes those drops the graphs
+void drop_iteration_graphs(admm_hip_ctx *ctx) {
     if (ctx->iter_exec) { (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr; }
     if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
+    if (ctx->frame_exec) { (void)hipGraphExecDestroy(ctx->frame_exec); ctx->frame_exec = nullptr; }
+    if (ctx->frame_graph) { (void)hipGraphDestroy(ctx->frame_graph); ctx->frame_graph = nullptr; }
+    ctx->frame_iters = 0;
+}
+
+void free_device(admm_hip_ctx *ctx) {
+    drop_iteration_graphs(ctx);
     for (int q = 0; q < 3; ++q) {
         if (ctx->pipe_exec[q]) { (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; }
         if (ctx->pipe_graph_h[q]) { (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }
@@ -1821,6 +1832,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_FRAME_GRAPH")) ctx->frame_graph_on = atoi(g) != 0;      // 0: one graph launch per ADMM iteration instead of one per frame
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8 || v == 16) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);
     if (const char *g = getenv("ADMM_HIP_TET_ORDER")) ctx->tet_order = atoi(g) != 0;
@@ -2296,6 +2308,26 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
             if (hipGraphInstantiate(&ctx->iter_exec, g, nullptr, nullptr, 0) != hipSuccess) { ctx->iter_exec = nullptr; (void)hipGraphDestroy(g); ctx->iter_graph = nullptr; (void)hipGetLastError(); ctx->graph_enabled = false; }
         }
     }
+    // the frame's whole loop as one graph (no timing events inside; iteration counts beyond 64 keep the per-iteration graph)
+    const bool use_frame_graph = use_graph && ctx->iter_exec && ctx->frame_graph_on && !ctx->timing && admm_iters >= 2 && admm_iters <= 64 && !(ctx->pipe > 1);
+    if (use_frame_graph && (!ctx->frame_exec || ctx->frame_iters != admm_iters)) {
+        if (ctx->frame_exec) { (void)hipGraphExecDestroy(ctx->frame_exec); ctx->frame_exec = nullptr; }
+        if (ctx->frame_graph) { (void)hipGraphDestroy(ctx->frame_graph); ctx->frame_graph = nullptr; }
+        const hipError_t be = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        int rc = be == hipSuccess ? ADMM_OK : ADMM_ERR_HIP;
+        for (int it = 0; it < admm_iters && !rc; ++it) {
+            rc = launch_local(ctx);
+            if (!rc) rc = launch_rhs(ctx);
+            if (!rc && ctx->world > 1 && ctx->levels_top.empty()) rc = do_allreduce(ctx, ctx->d_y, (int64_t)n3);
+            if (!rc) rc = launch_solve(ctx, nullptr);
+        }
+        hipGraph_t g = nullptr;
+        const hipError_t ce = be == hipSuccess ? hipStreamEndCapture(ctx->stream, &g) : be;
+        if (rc || ce != hipSuccess || !g || hipGraphInstantiate(&ctx->frame_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError(); ctx->frame_exec = nullptr; ctx->frame_graph_on = false;      // the per-iteration graph stays
+        } else { ctx->frame_graph = g; ctx->frame_iters = admm_iters; }
+    }
     ctx->res_n = 0;
     int iters_done = 0;
     const int stride = std::max(1, ctx->timing_stride);
@@ -2309,7 +2341,8 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         TRY(mark(ctx));
         return ADMM_OK;
     }
-    for (int it = 0; it < admm_iters; ++it) {
+    if (use_frame_graph && ctx->frame_exec && ctx->frame_iters == admm_iters) { HIPCHK(hipGraphLaunch(ctx->frame_exec, ctx->stream)); iters_done = admm_iters; }
+    for (int it = iters_done; it < admm_iters; ++it) {
         // the sampled iterations rotate from frame to frame: an iteration's cost depends on its position in the frame (the first
         // ones after the prologue do the most line-search work), a fixed phase would bias the average
         const bool timed = ctx->timing && ((it + ctx->timing_frame) % stride == stride - 1);
@@ -2523,8 +2556,7 @@ int admm_hip_keep_z(admm_hip_ctx *ctx, int on) {
     if (!ctx) return ADMM_ERR_ARG;
     if (getenv("ADMM_HIP_KEEP_Z")) return ADMM_OK;      // the environment decides
     if (ctx->keep_z_user != (on != 0)) {      // captured iterations carry the flag in their kernel arguments: capture again
-        if (ctx->iter_exec) { (void)hipGraphExecDestroy(ctx->iter_exec); ctx->iter_exec = nullptr; }
-        if (ctx->iter_graph) { (void)hipGraphDestroy(ctx->iter_graph); ctx->iter_graph = nullptr; }
+        drop_iteration_graphs(ctx);
         for (int q = 0; q < 3; ++q) {
             if (ctx->pipe_exec[q]) { (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; }
             if (ctx->pipe_graph_h[q]) { (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }

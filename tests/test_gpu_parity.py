@@ -661,6 +661,26 @@ def test_graph_replay_matches_eager_launches(pkg, monkeypatch):
     assert np.array_equal(out[0], out[1])
 
 
+def test_frame_graph_matches_per_iteration_graph(pkg, monkeypatch):
+    """Below 100k nodes the whole ADMM loop of a frame is ONE captured graph (one launch per frame); same kernels in the same order as
+    one graph launch per iteration and as eager launches: bitwise equal, also when the iteration count changes between calls (the
+    frame graph is captured again) and on a scene above the dense-solve limit (panel sweeps inside the graph)."""
+    for dims, dense_max in (((3, 3, 10), None), ((6, 6, 30), "0")):
+        out = []
+        for mode in ("frame", "iteration", "eager"):
+            monkeypatch.setenv("ADMM_HIP_FRAME_GRAPH", "1" if mode == "frame" else "0")
+            monkeypatch.setenv("ADMM_HIP_GRAPH", "0" if mode == "eager" else "1")
+            if dense_max is not None: monkeypatch.setenv("ADMM_HIP_DENSE_MAX", dense_max)
+            s = pkg.make_bar_system(*dims, kind=KIND["TET_NH"])
+            s.initialize()
+            for iters in (20, 20, 7, 1, 20):
+                s.step(iters)
+            out.append(s.m_x.copy())
+            del s
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+        monkeypatch.delenv("ADMM_HIP_DENSE_MAX", raising=False)
+
+
 def test_edge_cases(pkg):
     # empty batches, a single element, moving anchors (active and released)
     s = pkg.System(device_id=0); s.set_timestep(0.04)
