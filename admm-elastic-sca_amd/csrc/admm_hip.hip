@@ -183,6 +183,7 @@ struct admm_hip_ctx {
     // the whole ADMM loop of a frame as ONE graph (one launch per frame instead of one per iteration: the ~5-9 us between two graph
     // launches are 5-15 % of an iteration on small and mid-size scenes); captured for the iteration count of the call, again when it changes
     bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0;
+    int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
     // instead of a second round of workgroups for the few that did not fit (1M-tet bar: levels 3, 4, 6, 7 with 8.6-13.7 k columns:
@@ -1481,10 +1482,18 @@ int launch_solve(admm_hip_ctx *ctx, hipEvent_t mid, hipEvent_t ex0 = nullptr, hi
 #undef ADMM_FWD_BIG
             }
             for (const LevelDev::Root &R : L.roots) {      // roots: both sweeps as one product with the explicit inverse, straight into x
+                const dim3 pg((R.k + ROOT_ROWS - 1) / ROOT_ROWS), pb(64 * ROOT_ROWS);
+                const double *Sinv = ctx->d_panels + R.inv_off;
+                double *Xr = ctx->d_xcur + 3 * (size_t)R.first;
+                if (R.k <= ctx->root_fuse_k) {      // small root: every block of the product gathers t itself (one launch less)
+                    if (F.cg4) hipLaunchKernelGGL((root_product_kernel<true, true>), pg, pb, 0, st, R.k, root_inv_ld(R.k), Sinv, (const double *)ctx->d_y, Xr, R.first, R.foff, F, (const double *)ctx->d_c);
+                    else hipLaunchKernelGGL((root_product_kernel<true, false>), pg, pb, 0, st, R.k, root_inv_ld(R.k), Sinv, (const double *)ctx->d_y, Xr, R.first, R.foff, F, (const double *)ctx->d_c);
+                    continue;
+                }
                 double *T = ctx->d_w + 3 * (size_t)R.first;      // the root's own slice of W is free: it has no backward launch
                 if (F.cg4) hipLaunchKernelGGL((root_gather_kernel<true>), dim3((R.k + 255) / 256), dim3(256), 0, st, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
                 else hipLaunchKernelGGL((root_gather_kernel<false>), dim3((R.k + 255) / 256), dim3(256), 0, st, R.k, R.first, R.foff, F, (const double *)ctx->d_y, (const double *)ctx->d_c, T);
-                hipLaunchKernelGGL(root_product_kernel, dim3((R.k + ROOT_ROWS - 1) / ROOT_ROWS), dim3(64 * ROOT_ROWS), 0, st, R.k, root_inv_ld(R.k), (const double *)(ctx->d_panels + R.inv_off), (const double *)T, ctx->d_xcur + 3 * (size_t)R.first);
+                hipLaunchKernelGGL((root_product_kernel<false, false>), pg, pb, 0, st, R.k, root_inv_ld(R.k), Sinv, (const double *)T, Xr, 0, (int64_t)0, F, (const double *)nullptr);
             }
         }
     };
@@ -1832,6 +1841,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_ROOT_FUSE_K")) ctx->root_fuse_k = std::min(atoi(g), (int)admm_dev::ROOT_KCHUNK);
     if (const char *g = getenv("ADMM_HIP_FRAME_GRAPH")) ctx->frame_graph_on = atoi(g) != 0;      // 0: one graph launch per ADMM iteration instead of one per frame
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8 || v == 16) ctx->bwd_small_nw = v; }
     if (const char *g = getenv("ADMM_HIP_XCD")) ctx->xcd_min_supernodes = atoi(g);

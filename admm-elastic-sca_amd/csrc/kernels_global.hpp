@@ -751,7 +751,11 @@ constexpr int ROOT_ROWS = ADMM_ROOT_ROWS;
 #ifndef ADMM_ROOT_NT
 #define ADMM_ROOT_NT 1
 #endif
-__global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X) {
+// GATHER (roots of at most ROOT_KCHUNK columns): every block forms t = y - (children's contributions) itself instead of reading the T a
+// root_gather_kernel launch wrote -- one launch less where a launch is 4-5 us of pure latency (mid-size systems); T then carries y.
+template <bool GATHER, bool CG2>
+__global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X,
+                                                                      int first, int64_t foff, FactorDev F, const double *__restrict__ C) {
     __shared__ double ts[ROOT_KCHUNK * 3 + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROOT_ROWS + wave;
@@ -760,6 +764,14 @@ __global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int
     for (int c0 = 0; c0 < k; c0 += ROOT_KCHUNK) {
         const int kc = min(ROOT_KCHUNK, k - c0);
         __syncthreads();
+        if (GATHER) {
+            for (int q = threadIdx.x; q < kc; q += 64 * ROOT_ROWS) {
+                double s0, s1, s2;
+                child_sum<CG2>(F, foff + c0 + q, C, s0, s1, s2);
+                const double *src = T + 3 * (size_t)(first + c0 + q);
+                ts[3 * q] = src[0] - s0; ts[3 * q + 1] = src[1] - s1; ts[3 * q + 2] = src[2] - s2;
+            }
+        } else
         for (int q = threadIdx.x; q < 3 * kc; q += 64 * ROOT_ROWS) ts[q] = T[3 * (size_t)c0 + q];
         if (kc & 1) { if (threadIdx.x < 3) ts[3 * kc + threadIdx.x] = 0.0; }      // the pair loads below may reach one column past an odd chunk (padding of the row: finite)
         __syncthreads();
