@@ -183,6 +183,11 @@ struct admm_hip_ctx {
     // the whole ADMM loop of a frame as ONE graph (one launch per frame instead of one per iteration: the ~5-9 us between two graph
     // launches are 5-15 % of an iteration on small and mid-size scenes); captured for the iteration count of the call, again when it changes
     bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0;
+    // local step of scenes with several large batches (tets of two materials, cloth triangles, hinges ...): the batches are independent
+    // (own elements, own slots), so every large one can get its own stream and the launches' tails overlap (ADMM_HIP_LOCAL_STREAMS=4; measured:
+    // the cross-stream dependencies cost 10-25 us each, the single launch above does better), small batches follow on the context's stream
+    bool local_multi = true;                      // the whole local step in ONE launch when the scene has several batches (project_multi_kernel; ADMM_HIP_LOCAL_MULTI=0: one launch per batch)
+    int local_streams_max = 1, local_streams_min_elems = 16384; std::vector<hipStream_t> local_side; std::vector<hipEvent_t> local_join; hipEvent_t local_fork = nullptr;
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
@@ -1353,9 +1358,67 @@ void tet_trace_next(hipStream_t st) {
 #endif
 // `group` >= 0 (pipeline groups, Batch::grp_ptr): only that group's elements of every batch, on stream `st`; group < 0 with a
 // group-major layout: group after group on one stream (the serial launch of the same layout)
+// the side streams of the concurrent batches (created outside stream capture: admm_hip_step / local_step_only call this first)
+int ensure_local_streams(admm_hip_ctx *ctx) {
+    int n_large = 0;
+    if (ctx->local_streams_max > 1)
+        for (const Batch &b : ctx->batches) if (b.kind != ADMM_KIND_GENERIC && b.grp_ptr.empty() && b.n_local >= ctx->local_streams_min_elems) ++n_large;
+    if (n_large < 2) return ADMM_OK;
+    while ((int)ctx->local_side.size() < std::min(n_large, ctx->local_streams_max) - 1) {
+        hipStream_t q; hipEvent_t e;
+        HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking)); ctx->local_side.push_back(q);
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->local_join.push_back(e);
+    }
+    if (!ctx->local_fork) HIPCHK(hipEventCreateWithFlags(&ctx->local_fork, hipEventDisableTiming));
+    return ADMM_OK;
+}
+
 int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStream_t st = nullptr, bool track = false) {
     using namespace admm_dev;
+    const bool plain = !st && only_batch < 0 && group < 0 && !track;
     if (!st) st = ctx->stream;
+    // concurrent batches: the second, third ... LARGE batch of the scene each on a side stream (fork after what is on the context's stream, join
+    // before the RHS gather); everything else, and everything in the special launch modes, on `st`
+    int n_large = 0, side_used = 0;
+    if (plain && ctx->local_streams_max > 1)
+        for (const Batch &b : ctx->batches) if (b.kind != ADMM_KIND_GENERIC && b.grp_ptr.empty() && b.n_local >= ctx->local_streams_min_elems) ++n_large;
+    const bool fan_out = n_large >= 2 && (int)ctx->local_side.size() >= std::min(n_large, ctx->local_streams_max) - 1 && ctx->local_fork;      // (streams: ensure_local_streams, outside any capture)
+    if (fan_out) HIPCHK(hipEventRecord(ctx->local_fork, ctx->stream));
+    hipStream_t const st_main = st;
+    // the whole local step in one launch: every batch a segment of project_multi_kernel's grid
+    if (plain && ctx->local_multi && !fan_out) {
+        MultiBatch mb{}; int blocks = 0; bool ok = true;
+        for (const Batch &b : ctx->batches) {
+            if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;
+            int code = -1;
+            switch (b.kind) {
+            case ADMM_KIND_TET_NH: code = max_lbfgs_iters(b) <= 5 ? MK_TET_NH : -1; break;
+            case ADMM_KIND_TET_STVK: code = max_lbfgs_iters(b) <= 5 ? MK_TET_STVK : -1; break;
+            case ADMM_KIND_TET_LINEAR: code = MK_TET_LINEAR; break;
+            case ADMM_KIND_TET_VOLUME: code = MK_TET_VOLUME; break;
+            case ADMM_KIND_ANCHOR: code = MK_ANCHOR; break;
+            case ADMM_KIND_SPRING: code = MK_SPRING; break;
+            case ADMM_KIND_BEND: code = MK_BEND; break;
+            case ADMM_KIND_TRI_STRAIN: code = MK_TRI_STRAIN; break;
+            case ADMM_KIND_TRI_AREA: code = MK_TRI_AREA; break;
+            case ADMM_KIND_TRI_FUNG: code = MK_TRI_FUNG; break;
+            case ADMM_KIND_COLLISION: code = MK_COLLISION; break;
+            default: break;
+            }
+            if (code < 0 || !b.grp_ptr.empty() || mb.n == MULTI_MAX) { ok = false; break; }
+            mb.b[mb.n] = batch_dev(ctx, b);
+            blocks += (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
+            mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
+        }
+        // (a tet batch followed by its anchors already is one launch: project_tet_kernel's tail)
+        const bool tet_plus_anchor = mb.n == 2 && mb.code[0] <= MK_TET_VOLUME && mb.code[1] == MK_ANCHOR && ctx->fuse_anchor_tail;
+        if (ok && mb.n >= 2 && !tet_plus_anchor) {
+            hipLaunchKernelGGL(project_multi_kernel, dim3(blocks), dim3(LOCAL_BLOCK), 0, st, mb, (const double *)ctx->d_xcur, (const ShapeTable *)ctx->d_shapes);
+            HIPCHK(hipGetLastError());
+            return ADMM_OK;
+        }
+    }
+    int large_seen = 0;
     bool skip_next = false;
     for (size_t bi = 0; bi < ctx->batches.size(); ++bi) {
         const Batch &b = ctx->batches[bi];
@@ -1363,6 +1426,14 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
         if (skip_next) { skip_next = false; continue; }                  // (an anchor batch that went out with the tets before it)
         if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;     // user-defined forces: generic_begin / generic_finish
         const bool grouped = !b.grp_ptr.empty();
+        st = st_main;
+        if (fan_out && !grouped && b.n_local >= ctx->local_streams_min_elems) {
+            const int lane = large_seen++ % std::min(n_large, ctx->local_streams_max);      // 0: the context's stream
+            if (lane > 0) {
+                st = ctx->local_side[lane - 1];
+                if (lane > side_used) { HIPCHK(hipStreamWaitEvent(st, ctx->local_fork, 0)); side_used = lane; }
+            }
+        }
         const int g_first = grouped ? (group >= 0 ? group : 0) : 0, g_last = grouped ? (group >= 0 ? group + 1 : (int)b.grp_ptr.size() - 1) : 1;
       for (int g = g_first; g < g_last; ++g) {
         BatchDev d = batch_dev(ctx, b);
@@ -1412,6 +1483,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
         }
       }
     }
+    for (int q = 0; q < side_used; ++q) { HIPCHK(hipEventRecord(ctx->local_join[q], ctx->local_side[q])); HIPCHK(hipStreamWaitEvent(st_main, ctx->local_join[q], 0)); }
     HIPCHK(hipGetLastError());
     return ADMM_OK;
 }
@@ -1841,6 +1913,9 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_LOCAL_MULTI")) ctx->local_multi = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_LOCAL_STREAMS")) ctx->local_streams_max = std::max(1, atoi(g));      // 1: every batch on the context's stream, one after the other
+    if (const char *g = getenv("ADMM_HIP_LOCAL_STREAMS_MIN")) ctx->local_streams_min_elems = atoi(g);
     if (const char *g = getenv("ADMM_HIP_ROOT_FUSE_K")) ctx->root_fuse_k = std::min(atoi(g), (int)admm_dev::ROOT_KCHUNK);
     if (const char *g = getenv("ADMM_HIP_FRAME_GRAPH")) ctx->frame_graph_on = atoi(g) != 0;      // 0: one graph launch per ADMM iteration instead of one per frame
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_NW")) { const int v = atoi(g); if (v == 2 || v == 4 || v == 8 || v == 16) ctx->bwd_small_nw = v; }
@@ -2268,6 +2343,7 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
     using namespace admm_dev;
     HIPCHK(hipSetDevice(ctx->device_id));
     const int n3 = 3 * ctx->n_nodes;
+    TRY(ensure_local_streams(ctx));
     // event layout (timing mode): E0 | prologue | E1 | per TIMED iteration: S local E rhs E allreduce E [exchange: E E] fwd E bwd E | Ea | epilogue | Eb
     ctx->ev_used = 0; ctx->ev_iters = admm_iters; ctx->ev_timed = 0; ctx->ev_pending = ctx->timing;
     TRY(mark(ctx));
@@ -2581,6 +2657,7 @@ namespace { struct KeepZ { admm_hip_ctx *c; bool old; explicit KeepZ(admm_hip_ct
 int admm_hip_local_step_only(admm_hip_ctx *ctx, const double *x_cur) {
     TRY(require_device(ctx));
     if (!x_cur) return ADMM_ERR_ARG;
+    TRY(ensure_local_streams(ctx));
     KeepZ kz(ctx);
     TRY(set_nodes(ctx, ctx->d_xcur, x_cur));
     TRY(generic_begin(ctx, ctx->d_xcur));

@@ -204,24 +204,17 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b,
     project_anchor_elem<TRACK>(b, x, b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x, (int)blockIdx.x);
 }
 
-template <int KIND, int M, bool TRACK = false>
-#if ADMM_TET_WAVES > 0
-__global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
-#else
-__global__ __launch_bounds__(LOCAL_BLOCK)
-#endif
-void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail, int tail_block0) {
+// one 64-tet block of a tet batch; lb = the block's number in the launch's range of this batch (workgroup -> block through b.order)
+template <int KIND, int M, bool TRACK>
+__device__ __forceinline__ void project_tet_block(const BatchDev &b, const double *__restrict__ x, const int lb, double *stage) {      // stage: (TRACK ? 6 : 3) * 256 doubles of LDS
     // TRACK (admm_hip_enable_residuals / set_tolerance): the primal and dual residuals of the element (reference: described at
     // System.cpp:64-65, paper Eq. 22-23) come out of the same registers -- r = W (Dx - z) = W (u_new - u_old), and the corners'
     // shares of s = D^T W^T W (z - z_prev) with z_prev read back from this kernel's own previous output -- instead of two
     // snapshot copies and two more passes over u and z (+20 % per iteration before).
-    // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
-    // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
-    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem<TRACK>(tail, x, tail.e0 + ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x, (int)blockIdx.x - tail_block0); return; }
     // Launch order by cost: a block's time depends on its slowest line search (2-4 or 20 evaluations, spatially clustered); in mesh
     // order the expensive blocks of the 1M-tet bar come last and the launch ends with a 50 us tail of a few hundred waves.  The blocks
     // that took longest in the last frame start first (order_by_cost_kernel, once per frame); results do not depend on the order.
-    const int blk = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+    const int blk = b.order ? b.order[lb] : lb;
     const unsigned long long t_begin = b.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int e = b.e0 + blk * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
@@ -314,7 +307,6 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
         // goes to its place in the block's LDS staging (corners sorted by node, then lane, then corner: pos4), then one lane per
         // distinct node sums the node's run front to back (fixed order: deterministic) and writes ONE 24-byte slot -- 1.1 KB of slot
         // traffic per block instead of 6 KB of scattered 8-byte stores, and a gather that reads ~6 slots per node instead of ~24.
-        __shared__ double stage[(TRACK ? 6 : 3) * 256];
         const unsigned int p4 = b.pos4[e];
         const unsigned long long act = __ballot(1);
         const int nact = __popcll(act), lane = threadIdx.x & 63;
@@ -359,13 +351,27 @@ void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail,
     if (b.cost && threadIdx.x == 0) b.cost[blk] += (unsigned int)(__builtin_amdgcn_s_memrealtime() - t_begin);
 }
 
+template <int KIND, int M, bool TRACK = false>
+#if ADMM_TET_WAVES > 0
+__global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
+#else
+__global__ __launch_bounds__(LOCAL_BLOCK)
+#endif
+void project_tet_kernel(BatchDev b, const double *__restrict__ x, BatchDev tail, int tail_block0) {
+    // the anchors that follow a tet batch ride along as the launch's last workgroups (tail.n = 0: none): one launch and one
+    // kernel boundary less per ADMM iteration (anchor kernel 4.9 us + 1.5 us between the launches at the 1M-tet bar)
+    if ((int)blockIdx.x >= tail_block0) { project_anchor_elem<TRACK>(tail, x, tail.e0 + ((int)blockIdx.x - tail_block0) * LOCAL_BLOCK + threadIdx.x, (int)blockIdx.x - tail_block0); return; }
+    __shared__ double stage[(TRACK ? 6 : 3) * 256];
+    project_tet_block<KIND, M, TRACK>(b, x, (int)blockIdx.x, stage);
+}
+
 // ---------------------------------------------------------------------------
 // CollisionForce, CollisionForce.cpp:38-70: one element per node, D = I;
 // the point Dx+u is pushed out of every analytic shape it penetrates, in list
 // order (CollisionFloor.hpp:51-58, CollisionSphere.hpp:50-66, CollisionCylinder.hpp:48-66)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) {
-    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+__device__ __forceinline__ void project_collision_block(const BatchDev &b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes, const int lb) {
+    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
     const int id = b.idx[e];
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev
 // ---------------------------------------------------------------------------
 // Spring, Force.cpp:52-71   (rows: x_a - x_b)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+__device__ __forceinline__ void project_spring_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
+    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
     const int ia = b.idx[2 * (size_t)e], ib = b.idx[2 * (size_t)e + 1];
@@ -440,8 +446,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b,
 // ---------------------------------------------------------------------------
 // BendForce, BendForce.cpp:131-161   rows (x0-x2, x3-x2, x1-x2)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+__device__ __forceinline__ void project_bend_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
+    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
     const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
@@ -492,8 +498,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, c
 // FungTriangle (:227-249) need the singular values and vectors themselves: they run the bit-exact
 // restatement of Eigen's 3x2 JacobiSVD (local_math.hpp svd32).
 template <int MODE>
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) {
-    const int e = b.e0 + blockIdx.x * LOCAL_BLOCK + threadIdx.x;
+__device__ __forceinline__ void project_tri_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
+    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
     const int i0 = b.idx[4 * (size_t)e], i1 = b.idx[4 * (size_t)e + 1], i2 = b.idx[4 * (size_t)e + 2];
@@ -560,6 +566,50 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)b.dst[4 * (size_t)e + c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
+}
+
+// ---------------------------------------------------------------------------
+// the kernels: one batch per launch ...
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) { project_collision_block(b, x, shapes, (int)blockIdx.x); }
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b, const double *__restrict__ x) { project_spring_block(b, x, (int)blockIdx.x); }
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) { project_bend_block(b, x, (int)blockIdx.x); }
+template <int MODE>
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) { project_tri_block<MODE>(b, x, (int)blockIdx.x); }
+
+// ... or the WHOLE local step of a scene with several batches in ONE launch (System.cpp:57-58 is one loop over all forces): the
+// batches' blocks back to back in list order.  Launched one after the other, every batch ends with a tail of a few slow waves on a
+// mostly idle chip (two tet materials, cloth triangles and hinges of BASELINE configs[4]: 108 + 61 + 31 + 16 + 5 us); in one launch
+// the next batch's blocks fill the slots the tail leaves.  Side streams do the same but pay 10-25 us per cross-stream dependency.
+// Same per-element arithmetic, own outputs per element: bitwise the same results.
+constexpr int MULTI_MAX = 8;
+enum { MK_TET_NH = 0, MK_TET_STVK, MK_TET_LINEAR, MK_TET_VOLUME, MK_ANCHOR, MK_SPRING, MK_BEND, MK_TRI_STRAIN, MK_TRI_AREA, MK_TRI_FUNG, MK_COLLISION };
+struct MultiBatch { int n; int code[MULTI_MAX]; int blk_end[MULTI_MAX]; BatchDev b[MULTI_MAX]; };
+#if ADMM_TET_WAVES > 0
+__global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)
+#else
+__global__ __launch_bounds__(LOCAL_BLOCK)
+#endif
+void project_multi_kernel(MultiBatch a, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) {
+    __shared__ double stage[3 * 256];      // the tet blocks' staging of the RHS shares (one buffer for all four tet kinds)
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) ++i;
+    const int lb = (int)blockIdx.x - (i ? a.blk_end[i - 1] : 0);
+    const BatchDev &b = a.b[i];
+    switch (a.code[i]) {
+    case MK_TET_NH: project_tet_block<0, 5, false>(b, x, lb, stage); break;
+    case MK_TET_STVK: project_tet_block<1, 5, false>(b, x, lb, stage); break;
+    case MK_TET_LINEAR: project_tet_block<2, 1, false>(b, x, lb, stage); break;
+    case MK_TET_VOLUME: project_tet_block<3, 1, false>(b, x, lb, stage); break;
+    case MK_ANCHOR: project_anchor_elem<false>(b, x, b.e0 + lb * LOCAL_BLOCK + threadIdx.x, lb); break;
+    case MK_SPRING: project_spring_block(b, x, lb); break;
+    case MK_BEND: project_bend_block(b, x, lb); break;
+    case MK_TRI_STRAIN: project_tri_block<0>(b, x, lb); break;
+    case MK_TRI_AREA: project_tri_block<1>(b, x, lb); break;
+    case MK_TRI_FUNG: project_tri_block<2>(b, x, lb); break;
+    case MK_COLLISION: project_collision_block(b, x, shapes, lb); break;
+    default: break;
+    }
 }
 
 // ---------------------------------------------------------------------------

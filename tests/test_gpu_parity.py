@@ -681,6 +681,25 @@ def test_frame_graph_matches_per_iteration_graph(pkg, monkeypatch):
         monkeypatch.delenv("ADMM_HIP_DENSE_MAX", raising=False)
 
 
+def test_one_launch_local_step_matches_one_launch_per_batch(pkg, monkeypatch):
+    """Scenes with several batches run their whole local step as ONE launch (project_multi_kernel: the batches' blocks back to back);
+    same per-element arithmetic, own outputs per element: bitwise equal to one launch per batch, and to the batches on side streams --
+    the small mixed scene (NH + StVK tets, cloth triangles, hinges, anchors: five kinds), eager and graph-replayed."""
+    out = []
+    for env in ({"ADMM_HIP_LOCAL_MULTI": "1"}, {"ADMM_HIP_LOCAL_MULTI": "0"}, {"ADMM_HIP_LOCAL_MULTI": "0", "ADMM_HIP_LOCAL_STREAMS": "4", "ADMM_HIP_LOCAL_STREAMS_MIN": "64"},
+                {"ADMM_HIP_LOCAL_MULTI": "1", "ADMM_HIP_GRAPH": "0"}):
+        for k in ("ADMM_HIP_LOCAL_MULTI", "ADMM_HIP_LOCAL_STREAMS", "ADMM_HIP_LOCAL_STREAMS_MIN", "ADMM_HIP_GRAPH"): monkeypatch.delenv(k, raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        s, _ = pkg.make_mixed_system(4, 4, 12, 12, 12)
+        s.initialize()
+        for _ in range(3): s.step(10)
+        out.append((s.m_x.copy(), [s.read_local(b)["u"].copy() for b in range(len(s.batches))]))
+        del s
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0])
+        for a, b in zip(out[0][1], o[1]): assert np.array_equal(a, b)
+
+
 def test_edge_cases(pkg):
     # empty batches, a single element, moving anchors (active and released)
     s = pkg.System(device_id=0); s.set_timestep(0.04)
