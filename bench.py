@@ -395,13 +395,20 @@ def main():
     fwd_s = phase["solve_fwd_ms"] * 1e-3 / iters_total
     bwd_s = phase["solve_bwd_ms"] * 1e-3 / iters_total
     panel_bytes = info["nnz_L"] * 8.0 + info["n_nodes"] * 24.0 * 3
+    local_name, local_bytes = "project_tet_kernel<NH>", LOCAL_BYTES_PER_TET * (n_tets / world)
+    if a.config == "mixed":      # one launch for all batches (project_multi_kernel): SURVEY 8(d)'s bytes per element of every kind in the scene
+        per_kind = {"TET_NH": 472.0, "TET_STVK": 472.0, "TET_LINEAR": 472.0, "TET_VOLUME": 472.0, "TRI_STRAIN": 284.0, "TRI_AREA": 284.0, "TRI_FUNG": 284.0,
+                    "BEND": 368.0, "SPRING": 144.0, "ANCHOR": 124.0, "COLLISION": 124.0}
+        names = {v: k for k, v in pkg.KIND.items()}
+        local_name = "project_multi_kernel (the scene's whole local step: " + " + ".join("%d %s" % (n, names.get(k, str(k))) for k, n in s.batches) + ")"
+        local_bytes = sum(per_kind.get(names.get(k, ""), 472.0) * n for k, n in s.batches) / world
     cands = {
-        "project_tet_kernel<NH>": (LOCAL_BYTES_PER_TET * (n_tets / world), local_s),
+        local_name: (local_bytes, local_s),
         "solve_fwd (gather+panel kernels, all levels)": (panel_bytes, fwd_s),
         "solve_bwd_kernel (all levels)": (panel_bytes, bwd_s),
     }
     if world > 1 and a.shard == "subtree":      # a rank streams only its own subtrees' panels + the top: no per-rank byte count is kept
-        cands = {k: v for k, v in cands.items() if k.startswith("project_tet_kernel")}
+        cands = {k: v for k, v in cands.items() if k.startswith("project_")}
     dom = max(cands, key=lambda k: cands[k][1])
     by, sec = cands[dom]
     ach = by / sec / 1e9 if sec > 0 else 0.0
@@ -461,6 +468,7 @@ def main():
                      "what": "SURVEY 8(d) algorithmic bytes -- tet kernel 472 B/tet + RHS assembly 96 B/tet + 48 B/node + the factor panels and vectors once per sweep -- over the mean "
                              "ADMM iteration (HIP events, total_ms); bytes_min: what the round-3 kernels must move at the least (400 B/tet without z, one 24-byte slot per (64-tet block, node) "
                              "written and read once)"}
+    if dom.startswith("project_multi_kernel"): bound = "valu"      # the same fp64 prox arithmetic as the tet kernel (no counter passes are kept for this scene: valu stays null)
     roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
             "bytes_per_launch_min": (LOCAL_BYTES_PER_TET_MIN * (n_tets / world) if dom.startswith("project_tet_kernel") else by),
