@@ -1960,6 +1960,9 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (hipEvent_t e : ctx->pipe_ev_sw) (void)hipEventDestroy(e);
         if (ctx->pipe_ev_top) (void)hipEventDestroy(ctx->pipe_ev_top);
         for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
+        for (hipStream_t st : ctx->local_side) (void)hipStreamDestroy(st);
+        for (hipEvent_t e : ctx->local_join) (void)hipEventDestroy(e);
+        if (ctx->local_fork) (void)hipEventDestroy(ctx->local_fork);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         for (hipEvent_t e : ctx->ev_join) (void)hipEventDestroy(e);
         if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
