@@ -90,6 +90,26 @@ def test_factor_solves_assembled_system(pkg, dims, leaf, monkeypatch):
     assert np.abs(s.apply_A(v) - y).max() < 1e-10 * np.abs(y).max()
 
 
+@pytest.mark.parametrize("env", [{"ADMM_HIP_MERGE": "0", "ADMM_HIP_MERGE_ROOT": "0"}, {"ADMM_HIP_MERGE": "0"}, {"ADMM_HIP_MERGE": "50"}, {"ADMM_HIP_MERGE": "50", "ADMM_HIP_MERGE_DEPTH": "3"},
+                                 {"ADMM_HIP_MERGE": "0", "ADMM_HIP_MERGE_SMALL": "200"}])
+def test_tree_shapes_factor_and_solve(pkg, env, monkeypatch):
+    """Binary dissection tree, merged root, four-way nodes everywhere (the default below 160k nodes), eight-way nodes, four-way nodes only near the
+    leaves: every shape of the elimination tree factors and solves the assembled system; fewer levels with the merged shapes."""
+    monkeypatch.setenv("ADMM_HIP_LEAF", "8"); monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    for k, v in env.items(): monkeypatch.setenv(k, v)
+    s = pkg.make_bar_system(5, 5, 24, device_id=-1)
+    s.initialize()
+    n = s.n_nodes
+    b = np.random.default_rng(3).normal(size=3 * n)
+    x = s.debug_panel_solve_host(b)
+    assert np.abs(s.apply_A(x) - b).max() < 1e-11 * np.abs(b).max()
+    levels = s.info()["n_levels"]
+    if env.get("ADMM_HIP_MERGE") == "50":
+        monkeypatch.setenv("ADMM_HIP_MERGE", "0"); monkeypatch.setenv("ADMM_HIP_MERGE_ROOT", "0"); monkeypatch.delenv("ADMM_HIP_MERGE_DEPTH", raising=False)
+        s2 = pkg.make_bar_system(5, 5, 24, device_id=-1); s2.initialize()
+        assert levels < s2.info()["n_levels"]
+
+
 def test_mixed_scene_factor(pkg):
     g = golden("traj_cloth.npz")
     n = g["x"].shape[0]
