@@ -188,6 +188,8 @@ struct admm_hip_ctx {
     // the cross-stream dependencies cost 10-25 us each, the single launch above does better), small batches follow on the context's stream
     bool local_multi = true;                      // the whole local step in ONE launch when the scene has several batches (project_multi_kernel; ADMM_HIP_LOCAL_MULTI=0: one launch per batch)
     int local_streams_max = 1, local_streams_min_elems = 16384; std::vector<hipStream_t> local_side; std::vector<hipEvent_t> local_join; hipEvent_t local_fork = nullptr;
+    // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
+    int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
@@ -1090,6 +1092,7 @@ int upload_all(admm_hip_ctx *ctx) {
         TRY(upload(ctx, &ctx->d_xcur, px));
         TRY(dalloc(ctx, &ctx->d_mxbar, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_y, 3 * (size_t)n)); TRY(dalloc(ctx, &ctx->d_w, 3 * (size_t)n));
         TRY(upload(ctx, &ctx->d_perm, F.perm)); TRY(dalloc(ctx, &ctx->d_stage, 6 * (size_t)n));
+        TRY(upload(ctx, &ctx->d_iperm, F.iperm));
     }
     TRY(upload_factor(ctx));
     // batches: shard, sort corners, SoA upload
@@ -1913,6 +1916,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_STATE_DIRECT")) ctx->state_direct_max_nodes = atoi(g);      // systems up to that many nodes: upload_state / download_state without DMA (0: never)
     if (const char *g = getenv("ADMM_HIP_LOCAL_MULTI")) ctx->local_multi = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_LOCAL_STREAMS")) ctx->local_streams_max = std::max(1, atoi(g));      // 1: every batch on the context's stream, one after the other
     if (const char *g = getenv("ADMM_HIP_LOCAL_STREAMS_MIN")) ctx->local_streams_min_elems = atoi(g);
@@ -1954,6 +1958,8 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+        if (ctx->state_in_ev) (void)hipEventDestroy(ctx->state_in_ev);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
         for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
@@ -2541,11 +2547,38 @@ int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on) {
     if (e != hipSuccess) { (void)hipGetLastError(); return ADMM_ERR_HIP; }
     return ADMM_OK;
 }
+// small systems: the page-locked [x | v] buffer the state kernels address directly (NULL: use the DMA path)
+static double *state_buffer(admm_hip_ctx *ctx) {
+    if (ctx->n_nodes > ctx->state_direct_max_nodes || !ctx->d_iperm) return nullptr;
+    const size_t need = 6 * (size_t)ctx->n_nodes;
+    if (ctx->h_state_cap < need) {
+        if (ctx->h_state) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_state); ctx->h_state = nullptr; ctx->h_state_cap = 0; }
+        void *dev = nullptr;
+        if (hipHostMalloc((void **)&ctx->h_state, sizeof(double) * need, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, ctx->h_state, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->h_state) { (void)hipHostFree(ctx->h_state); ctx->h_state = nullptr; }
+            ctx->state_direct_max_nodes = 0;      // no mapped host memory here: the DMA path from now on
+            return nullptr;
+        }
+        ctx->h_state_dev = (double *)dev; ctx->h_state_cap = need;
+        if (!ctx->state_in_ev && hipEventCreateWithFlags(&ctx->state_in_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->state_direct_max_nodes = 0; return nullptr; }
+    }
+    return ctx->h_state;
+}
+
 int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v) {
     TRY(require_device(ctx));
     HIPCHK(hipSetDevice(ctx->device_id));
     const int n3 = 3 * ctx->n_nodes;
     const size_t bytes = sizeof(double) * (size_t)n3;
+    if (x && v) if (double *h = state_buffer(ctx)) {
+        if (ctx->state_in_pending) { HIPCHK(hipEventSynchronize(ctx->state_in_ev)); ctx->state_in_pending = false; }      // the previous upload has left the buffer
+        std::memcpy(h, x, bytes); std::memcpy(h + n3, v, bytes);
+        hipLaunchKernelGGL(admm_dev::state_in_kernel, dim3((2 * n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_iperm, (const double *)ctx->h_state_dev, ctx->d_x, ctx->d_v);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->state_in_ev, ctx->stream)); ctx->state_in_pending = true;
+        return ADMM_OK;
+    }
     if (x) {
         HIPCHK(hipMemcpyAsync(ctx->d_stage, x, bytes, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(admm_dev::permute_in_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_stage, ctx->d_x);
@@ -2562,6 +2595,14 @@ int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v) {
     HIPCHK(hipSetDevice(ctx->device_id));
     const int n3 = 3 * ctx->n_nodes;
     const size_t bytes = sizeof(double) * (size_t)n3;
+    if (x && v) if (double *h = state_buffer(ctx)) {
+        hipLaunchKernelGGL(admm_dev::state_out_kernel, dim3((2 * n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_iperm, (const double *)ctx->d_x, (const double *)ctx->d_v, ctx->h_state_dev);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // (also past any pending upload: the buffer is the host's again)
+        ctx->state_in_pending = false;
+        std::memcpy(x, h, bytes); std::memcpy(v, h + n3, bytes);
+        return ADMM_OK;
+    }
     if (x) {
         hipLaunchKernelGGL(admm_dev::permute_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_x, ctx->d_stage);
         HIPCHK(hipMemcpyAsync(x, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));

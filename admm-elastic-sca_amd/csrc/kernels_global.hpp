@@ -120,6 +120,21 @@ __global__ void permute_out_kernel(int n_nodes, const int *__restrict__ perm, co
     dst_caller[3 * (size_t)perm[node] + c] = src_factor[i];
 }
 
+// Small systems: the same frame boundary without any DMA -- the kernels read / write a page-locked host buffer directly (x then v, caller's
+// order, LINEAR on the host side: coalesced PCIe bursts; the permutation is on the device side).  iperm[node] = factor position of the caller's node.
+__global__ void state_in_kernel(int n_nodes, const int *__restrict__ iperm, const double *__restrict__ host_xv, double *__restrict__ x_factor, double *__restrict__ v_factor) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n3 = 3 * n_nodes;
+    if (i >= 2 * n3) return;
+    const int j = i < n3 ? i : i - n3, node = j / 3, c = j - 3 * node;
+    (i < n3 ? x_factor : v_factor)[3 * (size_t)iperm[node] + c] = host_xv[i];
+}
+__global__ void state_out_kernel(int n_nodes, const int *__restrict__ iperm, const double *__restrict__ x_factor, const double *__restrict__ v_factor, double *__restrict__ host_xv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n3 = 3 * n_nodes;
+    if (i >= 2 * n3) return;
+    const int j = i < n3 ? i : i - n3, node = j / 3, c = j - 3 * node;
+    host_xv[i] = (i < n3 ? x_factor : v_factor)[3 * (size_t)iperm[node] + c];
+}
+
 // One lane per dof: b = base + sum of the node's incident per-corner
 // contributions.  The local kernels write every corner's 24 bytes straight to
 // its slot (layouts: admm_hip.hip upload_all), summed here in fixed (batch, element, corner) order.

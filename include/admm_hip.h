@@ -203,7 +203,10 @@ int admm_hip_set_v(admm_hip_ctx *ctx, const double *v);
  * upload_state is asynchronous on the context's stream (x, v or both; NULL = leave the device copy), download_state
  * returns when both vectors have arrived.  One DMA per vector straight from / into the caller's memory; the
  * reordering to the factor's node order runs on the device.  admm_hip_pin_host page-locks (on = 1) or releases
- * (on = 0) a caller buffer so that these DMAs run at full PCIe rate without a staging copy.                      */
+ * (on = 0) a caller buffer so that these DMAs run at full PCIe rate without a staging copy.  Systems of up to 12 288
+ * nodes (ADMM_HIP_STATE_DIRECT), when both vectors travel: no DMA at all -- the vectors are copied by the host into / out of a
+ * page-locked buffer of the context that the permutation kernels address directly (the DMAs' submission latency is most
+ * of a small scene's frame boundary); upload_state has then read x and v when it returns.                          */
 /* (a refused registration returns ADMM_ERR_HIP without touching last_error or HIP's sticky error: the caller may go on
  * with pageable memory)                                                                                               */
 int admm_hip_pin_host(admm_hip_ctx *ctx, void *p, size_t bytes, int on);

@@ -1075,10 +1075,13 @@ def test_irregular_delaunay_mesh(pkg, monkeypatch):
     assert np.array_equal(xs[0], xs[1])                       # both slot layouts, bit for bit
 
 
-def test_state_boundary_and_sampled_timing(pkg):
+@pytest.mark.parametrize("direct", ["0", None])
+def test_state_boundary_and_sampled_timing(pkg, monkeypatch, direct):
     """The class API's frame boundary (admm_hip_upload_state / download_state: one DMA per vector out of / into page-locked
-    caller memory, reordering to the factor's node order on the device) against get/set; and timing events around every k-th
+    caller memory, reordering to the factor's node order on the device; systems of up to 12 288 nodes: NO DMA, the kernels address a
+    page-locked [x | v] buffer directly -- `direct`: both paths) against get/set; and timing events around every k-th
     iteration only: same trajectory bit for bit, phase sums scaled to the frame and consistent with the frame's real span."""
+    if direct is not None: monkeypatch.setenv("ADMM_HIP_STATE_DIRECT", direct)
     s = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"])
     s.initialize()
     ref = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"])

@@ -11,19 +11,21 @@ from __graft_entry__ import load_package
 pkg = load_package()
 sims = {}
 for name in ("class API",):
-    s = pkg.make_bar_system(32, 32, 163); s.keep_z(False); s.initialize()
+    dims = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 32, 163)
+    s = pkg.make_bar_system(*dims); s.keep_z(False); s.initialize()
     s.step(20); s.sync()
     hx = s.m_x.copy(); hv = s.m_v.copy(); s.pin_host(hx); s.pin_host(hv)
     sims[name] = (s, hx, hv)
+N = 6 if len(sys.argv) < 4 else 40
 for r in range(3):
     for name, (s, hx, hv) in sims.items():
         t = time.perf_counter()
-        for _ in range(6): s.upload_state(hx, hv); s.step(20); s.download_state(hx, hv)
-        tc = (time.perf_counter() - t) / 6
+        for _ in range(N): s.upload_state(hx, hv); s.step(20); s.download_state(hx, hv)
+        tc = (time.perf_counter() - t) / N
         t = time.perf_counter()
-        for _ in range(6): s.step(20)
-        s.sync(); tr = (time.perf_counter() - t) / 6
+        for _ in range(N): s.step(20)
+        s.sync(); tr = (time.perf_counter() - t) / N
         t = time.perf_counter()
-        for _ in range(6): s.upload_state(hx, hv); s.download_state(hx, hv)
-        tx = (time.perf_counter() - t) / 6
+        for _ in range(N): s.upload_state(hx, hv); s.download_state(hx, hv)
+        tx = (time.perf_counter() - t) / N
         print("round %d  %-12s class API %.3f ms/frame, resident %.3f: +%.2f %%; the four transfers alone %.3f ms" % (r, name, 1e3 * tc, 1e3 * tr, 100 * (tc / tr - 1), 1e3 * tx), flush=True)
