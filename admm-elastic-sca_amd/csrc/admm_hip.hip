@@ -190,6 +190,7 @@ struct admm_hip_ctx {
     int local_streams_max = 1, local_streams_min_elems = 16384; std::vector<hipStream_t> local_side; std::vector<hipEvent_t> local_join; hipEvent_t local_fork = nullptr;
     // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
     int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
+    bool tree_search = true;                       // pick the elimination tree of mid-size systems by the sweeps' cost model (ADMM_HIP_TREE_SEARCH=0: the rule-based tree)
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave
@@ -478,7 +479,49 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // (tools/probe/env_ab.py ADMM_HIP_MERGE_DEPTH 2 3, four alternations); 47.5k nodes +2 %, 63k and above +15 %: four-way there
         int merge_depth = (!own_subtrees && ctx->n_nodes >= 6000 && ctx->n_nodes < 30000) ? 3 : 2;
         if (const char *e = getenv("ADMM_HIP_MERGE_DEPTH")) merge_depth = atoi(e);
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth);
+        int root_depth = 0;
+        if (const char *e = getenv("ADMM_HIP_ROOT_DEPTH")) root_depth = atoi(e);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth);
+        // Tree search (systems between the dense limit and 160k nodes on one GPU, no ordering knob set by hand): the thresholds above were
+        // measured on bars; other shapes get the same trade-off from a cost model of the two sweeps fitted to 192 measured (scene, tree) pairs
+        // (tools/probe/tree_model_data.py, NOTES section E): 11.9 us per level below the roots (both sweeps: launch + dependent chain), 0.48 us per MB
+        // of panels (2 sweeps at ~4.2 TB/s), 0.18 us per MB of a root's explicit inverse (one product at ~5.7 TB/s); mean error 4-7 %, its pick
+        // within 5 % of the best of 24 trees on every held-out scene.  Candidates: leaves of 64 / 128 / 256, four- or eight-way nodes, the root
+        // spanning 4 bisection levels or not; ordering + symbolic analysis cost 2-60 ms each.  The rule-based tree stays unless the model
+        // sees at least 3 % in another one.
+        const bool by_hand = getenv("ADMM_HIP_LEAF") || getenv("ADMM_HIP_MERGE") || getenv("ADMM_HIP_MERGE_ROOT") || getenv("ADMM_HIP_MERGE_SMALL") || getenv("ADMM_HIP_MERGE_DEPTH") ||
+                             getenv("ADMM_HIP_ROOT_DEPTH") || ctx->leaf_size > 0 || ctx->merge_small > 0;
+        if (ctx->tree_search && !by_hand && !own_subtrees && ctx->world == 1 && ctx->n_nodes > ctx->dense_max && ctx->n_nodes < 160000) {
+            auto model_us = [&](const Factor &T) {
+                double us = 0.0;
+                for (const std::vector<int> &L : T.levels) {
+                    double mb = 0.0, inv_mb = 0.0; bool plain = false;
+                    for (int sn : L) {
+                        const Supernode &S = T.sn[sn];
+                        if (S.parent < 0 && S.ncols > ROOT_INV_MIN_COLS && ctx->root_inverse) inv_mb += 8e-6 * (double)S.ncols * root_inv_ld(S.ncols);
+                        else { plain = true; mb += 8e-6 * ((double)S.ncols * (S.ncols + 1) / 2 + (double)S.nrows * S.ncols); }
+                    }
+                    us += (plain ? 11.9 : 0.0) + 0.48 * mb + 0.176 * inv_mb;
+                }
+                return us;
+            };
+            const double base = model_us(ctx->F);
+            double best = base; Factor bestF; bool found = false;
+            const bool big = ctx->n_nodes >= 60000;
+            int tried = 0;
+            for (int lf : {64, 128, 256}) for (int dp : {2, 3}) for (int rd : {0, 4}) {
+                if (big && (lf == 128 || dp == 3)) continue;                     // (each analysis costs 30-60 ms there; eight-way nodes never paid above 50k nodes)
+                if (lf == leaf && dp == merge_depth && rd == root_depth && merge_above == 100) continue;      // the rule-based tree itself
+                Factor T;
+                analyze(ctx->A, xyz.data(), lf, T, 100, false, 0, dp, rd);
+                ++tried;
+                const double c = model_us(T);
+                if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: tree search: leaf %3d, %d-way nodes, root depth %d: %zu levels, model %.1f us per solve\n", lf, 1 << dp, rd, T.levels.size(), c);
+                if (c < best) { best = c; bestF = std::move(T); found = true; }
+            }
+            if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: tree search: rule-based tree %.1f us, best of %d others %.1f us -> %s\n", base, tried, best, (found && best < 0.97 * base) ? "taken" : "rule-based tree kept");
+            if (found && best < 0.97 * base) { const double t_o = ctx->F.t_order, t_s = ctx->F.t_symbolic; ctx->F = std::move(bestF); ctx->F.t_order += t_o; ctx->F.t_symbolic += t_s; }
+        }
     }
     // numeric phase: on the device when there is one (device_factorize, from upload_factor / recompute_weights); the small-system
     // inverse and device-less contexts (CPU tests of the host factorization) factor here
@@ -497,9 +540,9 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
     ctx->info.solve_contrib_rows = F.n_slots;
     if (getenv("ADMM_HIP_VERBOSE")) {
         for (size_t l = 0; l < F.levels.size(); ++l) {
-            int64_t e = 0, rws = 0; int mk = 0, small = 0;
-            for (int s : F.levels[l]) { const Supernode &S = F.sn[s]; e += (int64_t)S.ncols * (S.ncols + 1) / 2 + (int64_t)S.nrows * S.ncols; rws += S.ncols + S.nrows; mk = std::max(mk, S.ncols); small += S.ncols <= 64; }
-            fprintf(stderr, "admm_hip: level %2zu: %6zu supernodes (%d with k<=64), max k %4d, front rows %8lld, entries %10lld (%.1f MB)\n", l, F.levels[l].size(), small, mk, (long long)rws, (long long)e, e * 8e-6);
+            int64_t e = 0, rws = 0; int mk = 0, mf = 0, small = 0;
+            for (int s : F.levels[l]) { const Supernode &S = F.sn[s]; e += (int64_t)S.ncols * (S.ncols + 1) / 2 + (int64_t)S.nrows * S.ncols; rws += S.ncols + S.nrows; mk = std::max(mk, S.ncols); mf = std::max(mf, S.ncols + S.nrows); small += S.ncols <= 64; }
+            fprintf(stderr, "admm_hip: level %2zu: %6zu supernodes (%d with k<=64), max k %4d, max front %4d, front rows %8lld, entries %10lld (%.1f MB)\n", l, F.levels[l].size(), small, mk, mf, (long long)rws, (long long)e, e * 8e-6);
         }
     }
     ctx->info.t_order_s = F.t_order; ctx->info.t_symbolic_s = F.t_symbolic; ctx->info.t_numeric_s = F.t_numeric;
@@ -1918,6 +1961,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_BWD_NW")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16) ctx->bwd_nw = v; }
     if (const char *g = getenv("ADMM_HIP_FWD_SMALL_K")) ctx->fwd_small_k = atoi(g);
     if (const char *g = getenv("ADMM_HIP_BWD_SMALL_K")) ctx->bwd_small_k = atoi(g);
+    if (const char *g = getenv("ADMM_HIP_TREE_SEARCH")) ctx->tree_search = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_STATE_DIRECT")) ctx->state_direct_max_nodes = atoi(g);      // systems up to that many nodes: upload_state / download_state without DMA (0: never)
     if (const char *g = getenv("ADMM_HIP_LOCAL_MULTI")) ctx->local_multi = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_LOCAL_STREAMS")) ctx->local_streams_max = std::max(1, atoi(g));      // 1: every batch on the context's stream, one after the other

@@ -120,6 +120,7 @@ struct ND {
     int merge = 0;
     bool merge_root = false;
     int merge_small = 0;      // regions of at most that many nodes (and more than a leaf) become four-way nodes as well: one level less near the leaves
+    int root_depth = 0;       // > 1: bisection levels the ROOT node spans (whatever the other nodes do)
     int merge_depth = 2;      // bisection levels a merged node spans: 2 = four-way (three separators in one supernode), 3 = eight-way (seven)
     // the part `H` of a merged node: its separators down to `d` more bisections join `cols`, what is left below becomes children
     void gather(std::vector<int> &H, int d, int depth, std::vector<int> &kids, std::vector<int> &cols) {
@@ -134,7 +135,7 @@ struct ND {
     int rec(std::vector<int> &nodes, int depth = 0) {
         const int m = (int)nodes.size();
         if (m <= leaf) return emit(nodes);
-        bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small);
+        bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small) || (root_depth > 1 && depth == 0);
         std::vector<int> L, R, sep;
         bisect(nodes, L, R, sep);
         // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
@@ -143,7 +144,8 @@ struct ND {
         std::vector<int> cols;
         if (four) {
             // the merged node's own root (merge_root alone) stays four-way: its explicit inverse is sized for three separators
-            const int d = ((merge > 0 && m > merge) || (merge_small > 0 && m <= merge_small)) ? merge_depth : 2;
+            int d = ((merge > 0 && m > merge) || (merge_small > 0 && m <= merge_small)) ? merge_depth : 2;
+            if (depth == 0 && root_depth > 1) d = root_depth;      // the root alone spans more bisection levels: it is solved as one dense product with its explicit inverse
             gather(L, d - 1, depth + 1, kids, cols);
             gather(R, d - 1, depth + 1, kids, cols);
         } else {
@@ -158,7 +160,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -172,7 +174,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth);
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);

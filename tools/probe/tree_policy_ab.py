@@ -9,11 +9,11 @@ pkg = load_package()
 scenes = (((13, 13, 50), "TET_STVK"), ((10, 10, 30), "TET_NH"), ((20, 20, 60), "TET_NH"), ((24, 24, 100), "TET_NH"),
           ((22, 22, 70), "TET_NH"), ((24, 24, 75), "TET_NH"), ((28, 28, 120), "TET_NH"), ((32, 32, 163), "TET_NH"), ((26, 26, 123, 158, 158), "MIXED"))
 if os.environ.get("WALK_AB_SCENES"): scenes = tuple(scenes[int(i)] for i in os.environ["WALK_AB_SCENES"].split(","))
-variants = [("off", {"ADMM_HIP_WALK": "0"}), ("on", {"ADMM_HIP_WALK": "-1"})]
+variants = [("off", {"ADMM_HIP_WALK": "0"})]
 for extra in sys.argv[1:]:
     kv = dict(p.split("=") for p in extra.split(","))
     variants.append((extra, dict({"ADMM_HIP_WALK": "-1"}, **kv)))
-keys = ("ADMM_HIP_WALK", "ADMM_HIP_LEAF", "ADMM_HIP_MERGE", "ADMM_HIP_MERGE_DEPTH", "ADMM_HIP_MERGE_SMALL", "ADMM_HIP_WALK_MAX_ENTRIES", "ADMM_HIP_WALK_MAX_NODES")
+keys = ("ADMM_HIP_WALK", "ADMM_HIP_LEAF", "ADMM_HIP_MERGE", "ADMM_HIP_MERGE_DEPTH", "ADMM_HIP_MERGE_SMALL", "ADMM_HIP_ROOT_DEPTH", "ADMM_HIP_TREE_SEARCH", "ADMM_HIP_WALK_MAX_ENTRIES", "ADMM_HIP_WALK_MAX_NODES")
 for dims, kind in scenes:
     for name, env in variants:
         for k in keys: os.environ.pop(k, None)
