@@ -182,7 +182,7 @@ struct admm_hip_ctx {
     bool graph_enabled = true, graph_forced = false; hipGraph_t iter_graph = nullptr; hipGraphExec_t iter_exec = nullptr;
     // the whole ADMM loop of a frame as ONE graph (one launch per frame instead of one per iteration: the ~5-9 us between two graph
     // launches are 5-15 % of an iteration on small and mid-size scenes); captured for the iteration count of the call, again when it changes
-    bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0;
+    bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0, last_step_iters = -1;
     // local step of scenes with several large batches (tets of two materials, cloth triangles, hinges ...): the batches are independent
     // (own elements, own slots), so every large one can get its own stream and the launches' tails overlap (ADMM_HIP_LOCAL_STREAMS=4; measured:
     // the cross-stream dependencies cost 10-25 us each, the single launch above does better), small batches follow on the context's stream
@@ -2450,7 +2450,12 @@ int admm_hip_step(admm_hip_ctx *ctx, int admm_iters) {
         }
     }
     // the frame's whole loop as one graph (no timing events inside; iteration counts beyond 64 keep the per-iteration graph)
-    const bool use_frame_graph = use_graph && ctx->iter_exec && ctx->frame_graph_on && !ctx->timing && admm_iters >= 2 && admm_iters <= 64 && !(ctx->pipe > 1);
+    // (captured for an iteration count only once two calls in a row have asked for it: a caller that changes the count from frame to frame would
+    //  otherwise pay a graph instantiation per frame)
+    const bool same_count = admm_iters == ctx->last_step_iters;
+    ctx->last_step_iters = admm_iters;
+    const bool use_frame_graph = use_graph && ctx->iter_exec && ctx->frame_graph_on && !ctx->timing && admm_iters >= 2 && admm_iters <= 64 && !(ctx->pipe > 1) &&
+                                 (same_count || (ctx->frame_exec && ctx->frame_iters == admm_iters));
     if (use_frame_graph && (!ctx->frame_exec || ctx->frame_iters != admm_iters)) {
         if (ctx->frame_exec) { (void)hipGraphExecDestroy(ctx->frame_exec); ctx->frame_exec = nullptr; }
         if (ctx->frame_graph) { (void)hipGraphDestroy(ctx->frame_graph); ctx->frame_graph = nullptr; }
