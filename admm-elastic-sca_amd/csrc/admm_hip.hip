@@ -1436,7 +1436,19 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
     // the whole local step in one launch: every batch a segment of project_multi_kernel's grid
     if (plain && ctx->local_multi && !fan_out) {
         MultiBatch mb{}; int blocks = 0; bool ok = true;
-        for (const Batch &b : ctx->batches) {
+        // segments in the order of what a block costs, dearest first (the L-BFGS kinds, then the closed-form ones): the launch ends with the cheap
+        // blocks filling the slots the expensive ones leave -- whatever order the scene listed its forces in (results do not depend on the order)
+        auto dearness = [](int kind) {
+            switch (kind) {
+            case ADMM_KIND_TET_NH: return 0; case ADMM_KIND_TET_STVK: return 1; case ADMM_KIND_TRI_FUNG: return 2; case ADMM_KIND_TET_LINEAR: return 3; case ADMM_KIND_TET_VOLUME: return 4;
+            case ADMM_KIND_BEND: return 5; case ADMM_KIND_TRI_STRAIN: return 6; case ADMM_KIND_TRI_AREA: return 7; case ADMM_KIND_SPRING: return 8; default: return 9;
+            }
+        };
+        std::vector<const Batch *> seq;
+        for (const Batch &b : ctx->batches) seq.push_back(&b);
+        std::stable_sort(seq.begin(), seq.end(), [&](const Batch *a, const Batch *c) { return dearness(a->kind) < dearness(c->kind); });
+        for (const Batch *bp : seq) {
+            const Batch &b = *bp;
             if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;
             int code = -1;
             switch (b.kind) {
@@ -1459,7 +1471,12 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
             mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
         }
         // (a tet batch followed by its anchors already is one launch: project_tet_kernel's tail)
-        const bool tet_plus_anchor = mb.n == 2 && mb.code[0] <= MK_TET_VOLUME && mb.code[1] == MK_ANCHOR && ctx->fuse_anchor_tail;
+        bool tet_plus_anchor = false;
+        if (mb.n == 2 && mb.code[0] <= MK_TET_VOLUME && mb.code[1] == MK_ANCHOR && ctx->fuse_anchor_tail) {
+            std::vector<int> live;      // ... in list order: the tail rides along only when the anchors come right behind their tets
+            for (size_t bi = 0; bi < ctx->batches.size(); ++bi) if (ctx->batches[bi].n_local > 0 && ctx->batches[bi].kind != ADMM_KIND_GENERIC) live.push_back((int)bi);
+            tet_plus_anchor = live.size() == 2 && live[1] == live[0] + 1 && ctx->batches[live[1]].kind == ADMM_KIND_ANCHOR;
+        }
         if (ok && mb.n >= 2 && !tet_plus_anchor) {
             hipLaunchKernelGGL(project_multi_kernel, dim3(blocks), dim3(LOCAL_BLOCK), 0, st, mb, (const double *)ctx->d_xcur, (const ShapeTable *)ctx->d_shapes);
             HIPCHK(hipGetLastError());
