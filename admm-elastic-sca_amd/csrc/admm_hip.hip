@@ -509,14 +509,21 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
             double best = base; Factor bestF; bool found = false;
             const bool big = ctx->n_nodes >= 60000;
             int tried = 0;
+            struct Cand { int leaf, merge, depth, root_depth; bool merge_root; };
+            std::vector<Cand> cands;
             for (int lf : {64, 128, 256}) for (int dp : {2, 3}) for (int rd : {0, 4}) {
                 if (big && (lf == 128 || dp == 3)) continue;                     // (each analysis costs 30-60 ms there; eight-way nodes never paid above 50k nodes)
-                if (lf == leaf && dp == merge_depth && rd == root_depth && merge_above == 100) continue;      // the rule-based tree itself
+                cands.push_back({lf, 100, dp, rd, false});
+            }
+            if (big) cands.push_back({64, 0, 2, 0, ctx->root_inverse});          // the binary tree with the merged root (what the largest systems use): irregular meshes fill in faster under four-way nodes
+            for (const Cand &cd : cands) {
+                if (cd.leaf == leaf && cd.depth == merge_depth && cd.root_depth == root_depth && cd.merge == merge_above && cd.merge_root == merge_root) continue;      // the rule-based tree itself
                 Factor T;
-                analyze(ctx->A, xyz.data(), lf, T, 100, false, 0, dp, rd);
+                analyze(ctx->A, xyz.data(), cd.leaf, T, cd.merge, cd.merge_root, 0, cd.depth, cd.root_depth);
                 ++tried;
                 const double c = model_us(T);
-                if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: tree search: leaf %3d, %d-way nodes, root depth %d: %zu levels, model %.1f us per solve\n", lf, 1 << dp, rd, T.levels.size(), c);
+                if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: tree search: leaf %3d, %s nodes, root depth %d: %zu levels, model %.1f us per solve\n", cd.leaf,
+                                                        cd.merge ? (cd.depth == 3 ? "eight-way" : "four-way") : "binary", cd.root_depth, T.levels.size(), c);
                 if (c < best) { best = c; bestF = std::move(T); found = true; }
             }
             if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: tree search: rule-based tree %.1f us, best of %d others %.1f us -> %s\n", base, tried, best, (found && best < 0.97 * base) ? "taken" : "rule-based tree kept");
