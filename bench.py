@@ -309,7 +309,8 @@ def main():
     if a.config == "mixed":      # BASELINE.json configs[4]: 26x26x123 cubes = 498,888 tets (half NH, half StVK) + 158x158 sym-plane cloth
         if a.dims == [32, 32, 163]:
             nx, ny, nz = 26, 26, 123
-        s, _desc = pkg.make_mixed_system(nx, ny, nz, 158, 158, device_id=local_rank, rank=rank, world=world, stream=stream.cuda_stream, shard_mode=a.shard)
+        s, _desc = pkg.make_mixed_system(nx, ny, nz, 158, 158, device_id=local_rank, rank=int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0")) if fake_world > 1 else rank,
+                                         world=fake_world if fake_world > 1 else world, stream=stream.cuda_stream, shard_mode=a.shard)
         s.n_tets = s.n_elements
         a.no_cpu_baseline = True
     else:
