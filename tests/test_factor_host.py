@@ -110,6 +110,23 @@ def test_tree_shapes_factor_and_solve(pkg, env, monkeypatch):
         assert levels < s2.info()["n_levels"]
 
 
+@pytest.mark.parametrize("search", ["1", "0"])
+def test_tree_search_factor_solves(pkg, search, monkeypatch, capfd):
+    """Above the dense limit and with no ordering knob set, host_factor compares candidate elimination trees by the sweeps' cost model
+    (ADMM_HIP_TREE_SEARCH=0: the rule-based tree only); whatever tree it ends up with factors and solves the system -- a bar and a
+    two-body scene (two elimination-tree roots)."""
+    monkeypatch.setenv("ADMM_HIP_TREE_SEARCH", search); monkeypatch.setenv("ADMM_HIP_VERBOSE", "1")
+    for make in (lambda: pkg.make_bar_system(8, 8, 40, device_id=-1), lambda: pkg.make_mixed_system(6, 6, 24, 30, 30, device_id=-1)[0]):
+        s = make(); s.initialize()
+        assert s.info()["dense_solve"] == 0
+        n = s.n_nodes
+        b = np.random.default_rng(11).normal(size=3 * n)
+        x = s.debug_panel_solve_host(b)
+        assert np.abs(s.apply_A(x) - b).max() < 1e-10 * np.abs(b).max()
+    err = capfd.readouterr().err
+    assert ("tree search:" in err) == (search == "1")
+
+
 def test_mixed_scene_factor(pkg):
     g = golden("traj_cloth.npz")
     n = g["x"].shape[0]
