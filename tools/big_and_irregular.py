@@ -38,6 +38,13 @@ if "delaunay" in which:
     vol = np.einsum("ij,ij->i", e[:, 1] - e[:, 0], np.cross(e[:, 2] - e[:, 0], e[:, 3] - e[:, 0])) / 6.0
     tets[vol < 0] = tets[vol < 0][:, [0, 1, 3, 2]]
     tets = tets[np.abs(vol) > 1e-4 * np.abs(vol).mean()]
+    if os.environ.get("DELAUNAY_SORT"):      # experiment: the elements in Morton order of their centroids instead of scipy's order
+        c = pts[tets].mean(axis=1); q = ((c - c.min(0)) / (c.max(0) - c.min(0)) * 1023).astype(np.uint64)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
+            return v
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        tets = tets[np.argsort(key, kind="stable")]
     m = pkg.meshgen.lumped_tet_mass(pts, tets, 1000.0)
     s = pkg.System(device_id=0); s.set_timestep(0.04)
     s.add_nodes(pts.ravel(), np.repeat(m, 3))
