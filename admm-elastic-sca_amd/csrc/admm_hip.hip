@@ -1413,6 +1413,54 @@ void tet_trace_next(hipStream_t st) {
 #endif
 // `group` >= 0 (pipeline groups, Batch::grp_ptr): only that group's elements of every batch, on stream `st`; group < 0 with a
 // group-major layout: group after group on one stream (the serial launch of the same layout)
+// The scene's batches as segments of ONE project_multi_kernel launch (false: launch batch after batch -- a kind without a segment
+// body, more than MULTI_MAX batches, pipeline groups, or a tet batch with its anchors right behind it, which already is one launch).
+bool build_multi(admm_hip_ctx *ctx, admm_dev::MultiBatch &mb, int &blocks) {
+    using namespace admm_dev;
+    mb = MultiBatch{}; blocks = 0;
+    // segments in the order of what a block costs, dearest first (the L-BFGS kinds, then the closed-form ones) whatever order the scene listed
+    // its forces in (results do not depend on the order)
+    auto dearness = [](int kind) {
+        switch (kind) {
+        case ADMM_KIND_TET_NH: return 0; case ADMM_KIND_TET_STVK: return 1; case ADMM_KIND_TRI_FUNG: return 2; case ADMM_KIND_TET_LINEAR: return 3; case ADMM_KIND_TET_VOLUME: return 4;
+        case ADMM_KIND_BEND: return 5; case ADMM_KIND_TRI_STRAIN: return 6; case ADMM_KIND_TRI_AREA: return 7; case ADMM_KIND_SPRING: return 8; default: return 9;
+        }
+    };
+    std::vector<const Batch *> seq;
+    for (const Batch &b : ctx->batches) seq.push_back(&b);
+    std::stable_sort(seq.begin(), seq.end(), [&](const Batch *a, const Batch *c) { return dearness(a->kind) < dearness(c->kind); });
+    for (const Batch *bp : seq) {
+        const Batch &b = *bp;
+        if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;
+        int code = -1;
+        switch (b.kind) {
+        case ADMM_KIND_TET_NH: code = max_lbfgs_iters(b) <= 5 ? MK_TET_NH : -1; break;
+        case ADMM_KIND_TET_STVK: code = max_lbfgs_iters(b) <= 5 ? MK_TET_STVK : -1; break;
+        case ADMM_KIND_TET_LINEAR: code = MK_TET_LINEAR; break;
+        case ADMM_KIND_TET_VOLUME: code = MK_TET_VOLUME; break;
+        case ADMM_KIND_ANCHOR: code = MK_ANCHOR; break;
+        case ADMM_KIND_SPRING: code = MK_SPRING; break;
+        case ADMM_KIND_BEND: code = MK_BEND; break;
+        case ADMM_KIND_TRI_STRAIN: code = MK_TRI_STRAIN; break;
+        case ADMM_KIND_TRI_AREA: code = MK_TRI_AREA; break;
+        case ADMM_KIND_TRI_FUNG: code = MK_TRI_FUNG; break;
+        case ADMM_KIND_COLLISION: code = MK_COLLISION; break;
+        default: break;
+        }
+        if (code < 0 || !b.grp_ptr.empty() || mb.n == MULTI_MAX) return false;
+        mb.b[mb.n] = batch_dev(ctx, b);
+        blocks += (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
+        mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
+    }
+    if (mb.n < 2) return false;
+    if (mb.n == 2 && mb.code[0] <= MK_TET_VOLUME && mb.code[1] == MK_ANCHOR && ctx->fuse_anchor_tail) {
+        std::vector<int> live;      // ... in list order: the tail rides along only when the anchors come right behind their tets
+        for (size_t bi = 0; bi < ctx->batches.size(); ++bi) if (ctx->batches[bi].n_local > 0 && ctx->batches[bi].kind != ADMM_KIND_GENERIC) live.push_back((int)bi);
+        if (live.size() == 2 && live[1] == live[0] + 1 && ctx->batches[live[1]].kind == ADMM_KIND_ANCHOR) return false;
+    }
+    return true;
+}
+
 // the side streams of the concurrent batches (created outside stream capture: admm_hip_step / local_step_only call this first)
 int ensure_local_streams(admm_hip_ctx *ctx) {
     int n_large = 0;
@@ -1442,49 +1490,8 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
     hipStream_t const st_main = st;
     // the whole local step in one launch: every batch a segment of project_multi_kernel's grid
     if (plain && ctx->local_multi && !fan_out) {
-        MultiBatch mb{}; int blocks = 0; bool ok = true;
-        // segments in the order of what a block costs, dearest first (the L-BFGS kinds, then the closed-form ones): the launch ends with the cheap
-        // blocks filling the slots the expensive ones leave -- whatever order the scene listed its forces in (results do not depend on the order)
-        auto dearness = [](int kind) {
-            switch (kind) {
-            case ADMM_KIND_TET_NH: return 0; case ADMM_KIND_TET_STVK: return 1; case ADMM_KIND_TRI_FUNG: return 2; case ADMM_KIND_TET_LINEAR: return 3; case ADMM_KIND_TET_VOLUME: return 4;
-            case ADMM_KIND_BEND: return 5; case ADMM_KIND_TRI_STRAIN: return 6; case ADMM_KIND_TRI_AREA: return 7; case ADMM_KIND_SPRING: return 8; default: return 9;
-            }
-        };
-        std::vector<const Batch *> seq;
-        for (const Batch &b : ctx->batches) seq.push_back(&b);
-        std::stable_sort(seq.begin(), seq.end(), [&](const Batch *a, const Batch *c) { return dearness(a->kind) < dearness(c->kind); });
-        for (const Batch *bp : seq) {
-            const Batch &b = *bp;
-            if (b.n_local == 0 || b.kind == ADMM_KIND_GENERIC) continue;
-            int code = -1;
-            switch (b.kind) {
-            case ADMM_KIND_TET_NH: code = max_lbfgs_iters(b) <= 5 ? MK_TET_NH : -1; break;
-            case ADMM_KIND_TET_STVK: code = max_lbfgs_iters(b) <= 5 ? MK_TET_STVK : -1; break;
-            case ADMM_KIND_TET_LINEAR: code = MK_TET_LINEAR; break;
-            case ADMM_KIND_TET_VOLUME: code = MK_TET_VOLUME; break;
-            case ADMM_KIND_ANCHOR: code = MK_ANCHOR; break;
-            case ADMM_KIND_SPRING: code = MK_SPRING; break;
-            case ADMM_KIND_BEND: code = MK_BEND; break;
-            case ADMM_KIND_TRI_STRAIN: code = MK_TRI_STRAIN; break;
-            case ADMM_KIND_TRI_AREA: code = MK_TRI_AREA; break;
-            case ADMM_KIND_TRI_FUNG: code = MK_TRI_FUNG; break;
-            case ADMM_KIND_COLLISION: code = MK_COLLISION; break;
-            default: break;
-            }
-            if (code < 0 || !b.grp_ptr.empty() || mb.n == MULTI_MAX) { ok = false; break; }
-            mb.b[mb.n] = batch_dev(ctx, b);
-            blocks += (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
-            mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
-        }
-        // (a tet batch followed by its anchors already is one launch: project_tet_kernel's tail)
-        bool tet_plus_anchor = false;
-        if (mb.n == 2 && mb.code[0] <= MK_TET_VOLUME && mb.code[1] == MK_ANCHOR && ctx->fuse_anchor_tail) {
-            std::vector<int> live;      // ... in list order: the tail rides along only when the anchors come right behind their tets
-            for (size_t bi = 0; bi < ctx->batches.size(); ++bi) if (ctx->batches[bi].n_local > 0 && ctx->batches[bi].kind != ADMM_KIND_GENERIC) live.push_back((int)bi);
-            tet_plus_anchor = live.size() == 2 && live[1] == live[0] + 1 && ctx->batches[live[1]].kind == ADMM_KIND_ANCHOR;
-        }
-        if (ok && mb.n >= 2 && !tet_plus_anchor) {
+        MultiBatch mb{}; int blocks = 0;
+        if (build_multi(ctx, mb, blocks)) {
             hipLaunchKernelGGL(project_multi_kernel, dim3(blocks), dim3(LOCAL_BLOCK), 0, st, mb, (const double *)ctx->d_xcur, (const ShapeTable *)ctx->d_shapes);
             HIPCHK(hipGetLastError());
             return ADMM_OK;

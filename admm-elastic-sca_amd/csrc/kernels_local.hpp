@@ -177,27 +177,40 @@ __device__ __forceinline__ void project_anchor_elem(const BatchDev &b, const dou
     const int n = b.n;
     if (e >= b.e1) return;
     const int id = b.idx[e];
+    const int ds = b.dst[e];
     const double s = b.w2h2[e];
     const bool act = b.active[e] != 0;
+    const double w2 = TRACK ? b.w2[e] : 0.0;
+    // every load first, every store last (a load behind a store waits for it: coordinate by coordinate the element was three round trips long,
+    // and as the tail of a tet launch these blocks are the last ones to start)
+    double X[3], U[3], T[3], ZP[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        X[j] = x[3 * (size_t)id + j];
+        if (b.dx_override) X[j] = b.dx_override[(size_t)j * n + e];
+        U[j] = b.u[(size_t)j * n + e];
+        T[j] = act ? b.targets[3 * (size_t)e + j] : 0.0;
+        ZP[j] = TRACK ? b.z[(size_t)j * n + e] : 0.0;
+    }
     double r2 = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        double dx = 0.0 + 1.0 * x[3 * (size_t)id + j];
-        if (b.dx_override) dx = b.dx_override[(size_t)j * n + e];
-        const double u = b.u[(size_t)j * n + e];
+        double dx = 0.0 + 1.0 * X[j];
+        if (b.dx_override) dx = X[j];
+        const double u = U[j];
         double zi;
-        if (act) zi = b.targets[3 * (size_t)e + j];
+        if (act) zi = T[j];
         else { zi = dx + u; b.targets[3 * (size_t)e + j] = dx; }
         const double un = u + (dx - zi);
         if (TRACK) {      // s: the one corner's share w^2 (z - z_prev); r: w^2 |u_new - u_old|^2
             const double du = un - u;
             r2 += du * du;
-            b.res_slots[3 * (size_t)b.dst[e] + j] = 0.0 + 1.0 * (b.w2[e] * (zi - b.z[(size_t)j * n + e]));
+            b.res_slots[3 * (size_t)ds + j] = 0.0 + 1.0 * (w2 * (zi - ZP[j]));
         }
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
-        b.fslot[3 * (size_t)b.dst[e] + j] = s * (zi - un);
+        b.fslot[3 * (size_t)ds + j] = s * (zi - un);
     }
-    if (TRACK) track_block_sum(b.w2[e] * r2, &b.res_partial[blk]);
+    if (TRACK) track_block_sum(w2 * r2, &b.res_partial[blk]);
 }
 template <bool TRACK>
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_anchor_kernel(BatchDev b, const double *__restrict__ x) {
@@ -375,6 +388,7 @@ __device__ __forceinline__ void project_collision_block(const BatchDev &b, const
     const int n = b.n;
     if (e >= b.e1) return;
     const int id = b.idx[e];
+    const int ds = b.dst[e];      // (with the other loads: behind the u / z stores it would wait for them)
     const double s = b.w2h2[e];
     double dx[3], u[3], p[3];
 #pragma unroll
@@ -404,7 +418,7 @@ __device__ __forceinline__ void project_collision_block(const BatchDev &b, const
     for (int j = 0; j < 3; ++j) {
         const double un = u[j] + (dx[j] - p[j]);
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = p[j];
-        b.fslot[3 * (size_t)b.dst[e] + j] = s * (p[j] - un);
+        b.fslot[3 * (size_t)ds + j] = s * (p[j] - un);
     }
 }
 
@@ -416,6 +430,7 @@ __device__ __forceinline__ void project_spring_block(const BatchDev &b, const do
     const int n = b.n;
     if (e >= b.e1) return;
     const int ia = b.idx[2 * (size_t)e], ib = b.idx[2 * (size_t)e + 1];
+    const int da = b.dst[2 * (size_t)e], db = b.dst[2 * (size_t)e + 1];      // (with the other loads: behind the u / z stores they would wait for them)
     const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e], rest_length = b.rest[e];
     double dx[3], u[3], d[3];
 #pragma unroll
@@ -438,8 +453,8 @@ __device__ __forceinline__ void project_spring_block(const BatchDev &b, const do
         const double un = u[j] + (dx[j] - zi);
         b.u[(size_t)j * n + e] = un; b.z[(size_t)j * n + e] = zi;
         const double f = s * (zi - un);
-        b.fslot[3 * (size_t)b.dst[2 * (size_t)e] + j] = f;
-        b.fslot[3 * (size_t)b.dst[2 * (size_t)e + 1] + j] = -f;
+        b.fslot[3 * (size_t)da + j] = f;
+        b.fslot[3 * (size_t)db + j] = -f;
     }
 }
 
@@ -450,40 +465,61 @@ __device__ __forceinline__ void project_bend_block(const BatchDev &b, const doub
     const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
+    // every load first, every store last: the stores to u / z may alias the loads as far as the compiler knows, and a load behind a store waits
+    // for it (one in-order memory counter) -- per coordinate in turn the kernel was three dependent round trips long (31 us for 149 k hinges)
     const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
+    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
     const double a0 = b.rest[(size_t)0 * n + e], a1 = b.rest[(size_t)1 * n + e], a3 = b.rest[(size_t)3 * n + e];
     const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e];
-    const double den = a0 * a0 + a3 * a3 + a1 * a1;
-    const double cc = 1.0 / (w2 + st);
+    double U[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) U[q] = b.u[(size_t)q * n + e];
     const int plus[3] = {id.x, id.w, id.y};
+    double X2[3], XP[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double x2 = x[3 * (size_t)id.z + j];
+        X2[j] = x[3 * (size_t)id.z + j];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) XP[r][j] = x[3 * (size_t)plus[r] + j];
+    }
+    double DXO[9];
+    if (b.dx_override) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) DXO[q] = b.dx_override[(size_t)q * n + e];
+    }
+    const double den = a0 * a0 + a3 * a3 + a1 * a1;
+    const double cc = 1.0 / (w2 + st);
+    double UN[9], ZI[9], F[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double x2 = X2[j];
         double dx[3], u[3], d[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const double xp = x[3 * (size_t)plus[r] + j];
+            const double xp = XP[r][j];
             dx[r] = (plus[r] < id.z) ? ((0.0 + 1.0 * xp) + -1.0 * x2) : ((0.0 + -1.0 * x2) + 1.0 * xp);
-            if (b.dx_override) dx[r] = b.dx_override[(size_t)(3 * r + j) * n + e];
-            u[r] = b.u[(size_t)(3 * r + j) * n + e];
+            if (b.dx_override) dx[r] = DXO[3 * r + j];
+            u[r] = U[3 * r + j];
             d[r] = dx[r] + u[r];
         }
         const double lam = 2.0 * (a0 * d[0] + a3 * d[1] + a1 * d[2]) / den;
         const double p0 = d[0] - 0.5 * a0 * lam, p1 = d[1] - 0.5 * a3 * lam, p2 = d[2] - 0.5 * a1 * lam;
         const double pr[3] = {p0, p1, p2};
-        double f[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double zi = cc * (st * pr[r] + w2 * d[r]);
             const double un = u[r] + (dx[r] - zi);
-            b.u[(size_t)(3 * r + j) * n + e] = un; b.z[(size_t)(3 * r + j) * n + e] = zi;
-            f[r] = s * (zi - un);
+            UN[3 * r + j] = un; ZI[3 * r + j] = zi;
+            F[r][j] = s * (zi - un);
         }
-        // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
-        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 0] + j] = f[0];
-        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 1] + j] = f[2];
-        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 2] + j] = -((f[0] + f[1]) + f[2]);
-        b.fslot[3 * (size_t)b.dst[4 * (size_t)e + 3] + j] = f[1];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { b.u[(size_t)q * n + e] = UN[q]; b.z[(size_t)q * n + e] = ZI[q]; }
+    // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
+    double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o0[j] = F[0][j]; o1[j] = F[2][j]; o2[j] = -((F[0][j] + F[1][j]) + F[2][j]); o3[j] = F[1][j];
     }
 }
 
@@ -502,7 +538,9 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
     const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
     const int n = b.n;
     if (e >= b.e1) return;
-    const int i0 = b.idx[4 * (size_t)e], i1 = b.idx[4 * (size_t)e + 1], i2 = b.idx[4 * (size_t)e + 2];
+    const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
+    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];      // (with the other loads: behind the u / z stores it would wait for them)
+    const int i0 = id.x, i1 = id.y, i2 = id.z;
     double B[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) B[i] = b.rest[(size_t)i * n + e];
@@ -562,10 +600,11 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
         b.u[(size_t)i * n + e] = un; b.z[(size_t)i * n + e] = zi[i];
         q[i] = zi[i] - un;
     }
+    const int dsl[3] = {ds.x, ds.y, ds.z};
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)b.dst[4 * (size_t)e + c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
+        for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)dsl[c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -584,6 +623,8 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 // Same per-element arithmetic, own outputs per element: bitwise the same results.
 constexpr int MULTI_MAX = 8;
 enum { MK_TET_NH = 0, MK_TET_STVK, MK_TET_LINEAR, MK_TET_VOLUME, MK_ANCHOR, MK_SPRING, MK_BEND, MK_TRI_STRAIN, MK_TRI_AREA, MK_TRI_FUNG, MK_COLLISION };
+// (Tried: the segments' blocks interleaved in proportion through a workgroup -> (segment, block) table, so that the memory-bound blocks of the cheap kinds
+// share the SIMDs with the tet blocks all along the launch: local step of the mixed scene 0.178 -> 0.196 ms -- dearest first, back to back, is the better schedule.)
 struct MultiBatch { int n; int code[MULTI_MAX]; int blk_end[MULTI_MAX]; BatchDev b[MULTI_MAX]; };
 #if ADMM_TET_WAVES > 0
 __global__ __launch_bounds__(LOCAL_BLOCK, ADMM_TET_WAVES)

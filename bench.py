@@ -454,6 +454,18 @@ def main():
                         "issue_floor_ms": 1e3 * pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S,
                         "valu_frac": (pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S) / sec if sec > 0 else 0.0}
                 bound = "valu"
+        if a.config == "mixed" and world == 1 and dom.startswith("project_multi_kernel"):      # the scene's one-launch local step: counters of tools/pmc_collect.sh with PMC_MIXED=1
+            pmc_file = os.path.join("profiles", "r03", "pmc_mixed.json")
+            kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
+            pm = kern[[k for k in kern if "project_multi_kernel" in k][0]]
+            traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
+            busy = pm["SQ_ACTIVE_INST_VALU"]["per_launch"] / pm["SQ_WAVE_CYCLES"]["per_launch"]
+            valu = {"valu_insts_per_launch": pm["SQ_INSTS_VALU"]["per_launch"], "fma_f64_insts": pm["SQ_INSTS_VALU_FMA_F64"]["per_launch"],
+                    "valu_busy_per_wave": busy, "waves_per_simd": 2, "simd_valu_issue_frac": min(1.0, 2 * busy),
+                    "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"]),
+                    "issue_floor_ms": 1e3 * pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S,
+                    "valu_frac": (pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S) / sec if sec > 0 else 0.0}
+            bound = "valu"
     except Exception as e:  # noqa: BLE001 -- counters are side information
         traffic = None
         print("bench: PMC summary %s unusable: %r" % (pmc_file, e), file=sys.stderr)
