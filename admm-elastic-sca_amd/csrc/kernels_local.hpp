@@ -541,6 +541,9 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
     const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
     const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];      // (with the other loads: behind the u / z stores it would wait for them)
     const int i0 = id.x, i1 = id.y, i2 = id.z;
+    // (parameters with the first burst of loads, not after the SVD: one exposed round trip less in a wave whose life is memory latency)
+    const double kb = MODE != 2 ? b.kblend[e] : 0.0, w2e = MODE != 2 ? b.w2[e] : 0.0;
+    const double par1 = MODE != 2 ? b.par[(size_t)1 * n + e] : 0.0, par2 = MODE != 2 ? b.par[(size_t)2 * n + e] : 0.0, par3 = MODE != 2 ? b.par[(size_t)3 * n + e] : 0.0;
     double B[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) B[i] = b.rest[(size_t)i * n + e];
@@ -567,11 +570,11 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 3; ++i) T[i + 3 * j] = U2[i] * V[j] + U2[i + 3] * V[j + 2];
-        const double k = b.kblend[e], w2 = b.w2[e];
+        const double k = kb, w2 = w2e;
 #pragma unroll
         for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
-        if (b.par[(size_t)3 * n + e] != 0.0) {
-            const double lmin = b.par[(size_t)1 * n + e], lmax = b.par[(size_t)2 * n + e];
+        if (par3 != 0.0) {
+            const double lmin = par1, lmax = par2;
             const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
             const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
             const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
@@ -582,8 +585,8 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
         }
     } else if (MODE == 1) {
         double p[6];
-        project_triarea_p(d, (int)b.par[(size_t)1 * n + e], b.par[(size_t)2 * n + e], b.par[(size_t)3 * n + e], p);
-        const double k = b.kblend[e], w2 = b.w2[e];
+        project_triarea_p(d, (int)par1, par2, par3, p);
+        const double k = kb, w2 = w2e;
 #pragma unroll
         for (int i = 0; i < 6; ++i) zi[i] = (k * p[i] + w2 * d[i]) / (w2 + k);
     } else {
