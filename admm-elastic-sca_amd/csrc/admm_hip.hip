@@ -56,6 +56,7 @@ struct Batch {
     // tets: the corners' right-hand-side shares are summed per node inside every 64-tet block (LDS) before they go to the slots:
     // one slot per (block, node) instead of one per corner (project_tet_kernel's epilogue)
     bool prered = false;
+    int tpb = 64;      // tets per one-wave block (admm_hip_ctx::tet_tpb): 64, or fewer in under-filled launches -- the lanes beyond stay idle
     unsigned int *d_pos4 = nullptr; int *d_bn_ptr = nullptr, *d_bn_dst = nullptr; unsigned short *d_bn_end = nullptr;
     double *d_res_partial = nullptr; bool res_fused = false;           // tets: residuals come out of the projection kernel itself (one |r|^2 partial per 64-tet block)
     std::vector<double> G;                // [12][n_local] selector block per element, corners in device order
@@ -111,6 +112,7 @@ struct admm_hip_ctx {
     void *rccl_comm = nullptr; bool rccl_owned = false;      // ncclComm_t: the all-reduce is ncclAllReduce on the context's stream (takes precedence over the hook)
     admm_hip_host_allreduce_fn host_allreduce = nullptr; void *host_allreduce_user = nullptr;   // transport that sums HOST buffers (admm_hip_set_host_allreduce)
     double *h_comm = nullptr; size_t h_comm_cap = 0;          // its pinned staging
+    double *d_small = nullptr; size_t d_small_cap = 0;        // admm_hip_allreduce_host's device scratch
     bool finalized = false;
     int leaf_size = 0;                        // nested-dissection leaf size; 0 = by system size (host_factor)
     // host state
@@ -156,6 +158,8 @@ struct admm_hip_ctx {
     // the class mirror and the bench do -- stops storing it in admm_hip_step; the parity entry points (local_step_only / local_step_dx)
     // and residual tracking always store it.  ADMM_HIP_KEEP_Z=0 / 1 overrides.
     bool keep_z = true, keep_z_user = true;
+    int tet_lds_pad = 0;                      // ADMM_HIP_TET_LDS_PAD (probes only): unused dynamic LDS per tet block, caps the waves per SIMD (160 KB per CU)
+    int tet_tpb = 0;                          // ADMM_HIP_TPB: tets per one-wave block (8 / 16 / 32 / 64); 0 = chosen per batch from its size (upload_all)
     bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
     int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
     std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
@@ -1128,8 +1132,10 @@ int upload_factor(admm_hip_ctx *ctx) {
 static bool block_end(const Batch &b, int el) {
     int base = 0;
     if (!b.grp_ptr.empty()) { size_t g = 0; while (g + 2 < b.grp_ptr.size() && el >= b.grp_ptr[g + 1]) ++g; base = b.grp_ptr[g]; if (el + 1 == b.grp_ptr[g + 1]) return true; }
-    return (el - base) % admm_dev::LOCAL_BLOCK == admm_dev::LOCAL_BLOCK - 1;
+    return (el - base) % b.tpb == b.tpb - 1;
 }
+// number of launch blocks of a batch (tets: `tpb` elements per block; everything else LOCAL_BLOCK)
+static int batch_blocks(const Batch &b) { return b.grp_blk.empty() ? (b.n_local + b.tpb - 1) / b.tpb : b.grp_blk.back(); }
 
 int upload_all(admm_hip_ctx *ctx) {
     const double t0 = now_s();
@@ -1171,6 +1177,8 @@ int upload_all(admm_hip_ctx *ctx) {
             for (int e = 0; e < b.n_total; ++e) b.max_iter = std::max(b.max_iter, (int)b.params[(size_t)e * 3 + 2]);
         b.corner_perm.assign((size_t)b.n_total * nn, 0);
         b.prered = ctx->tet_prered && b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK;
+        b.tpb = admm_dev::LOCAL_BLOCK;
+        if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && b.grp_ptr.empty() && ctx->tet_tpb > 0) b.tpb = ctx->tet_tpb;
         std::vector<int> blk_nodes;       // prered: the nodes of the current 64-tet block
         for (int el = 0; el < b.n_local; ++el) {
             const int e = b.local[el];
@@ -1314,7 +1322,7 @@ int upload_all(admm_hip_ctx *ctx) {
         b.d_order = nullptr; b.d_cost = nullptr; b.n_blocks_ordered = 0;
         {
             // more blocks than the chip holds at once (2 waves x 4 SIMDs x 256 CUs): the launch order matters
-            const int nblk = b.grp_blk.empty() ? (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK : b.grp_blk.back();
+            const int nblk = batch_blocks(b);
             if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && ctx->tet_order && nblk > ctx->tet_order_min_blocks) {
                 std::vector<int> ident(nblk); std::iota(ident.begin(), ident.end(), 0);
                 for (size_t g = 0; g + 1 < b.grp_blk.size(); ++g) std::iota(ident.begin() + b.grp_blk[g], ident.begin() + b.grp_blk[g + 1], 0);      // per group: ids relative to the group's first block
@@ -1388,6 +1396,7 @@ BatchDev batch_dev(const admm_hip_ctx *ctx, const Batch &b) {
     d.order = b.d_order; d.cost = b.d_cost;
     d.res_slots = ctx->d_res_slots; d.res_partial = b.d_res_partial;
     d.pos4 = b.d_pos4; d.bn_ptr = b.d_bn_ptr; d.bn_dst = b.d_bn_dst; d.bn_end = b.d_bn_end;
+    d.tpb = b.tpb;
     return d;
 }
 
@@ -1449,7 +1458,7 @@ bool build_multi(admm_hip_ctx *ctx, admm_dev::MultiBatch &mb, int &blocks) {
         }
         if (code < 0 || !b.grp_ptr.empty() || mb.n == MULTI_MAX) return false;
         mb.b[mb.n] = batch_dev(ctx, b);
-        blocks += (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK;
+        blocks += batch_blocks(b);
         mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
     }
     if (mb.n < 2) return false;
@@ -1524,7 +1533,7 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
             if (d.bn_ptr) d.bn_ptr += b.grp_blk[g];
         }
         const bool trk = track && b.res_fused;
-        dim3 grid((d.e1 - d.e0 + LOCAL_BLOCK - 1) / LOCAL_BLOCK), block(LOCAL_BLOCK);
+        dim3 grid((d.e1 - d.e0 + b.tpb - 1) / b.tpb), block(LOCAL_BLOCK);
         const double *x = ctx->d_xcur;
         // an anchor batch right behind a tet batch rides along in the tet launch (project_tet_kernel's tail)
         BatchDev tail{}; const int tail_block0 = (int)grid.x;
@@ -1541,8 +1550,8 @@ int launch_local(admm_hip_ctx *ctx, int only_batch = -1, int group = -1, hipStre
 #ifdef ADMM_TET_PROFILE
             tet_trace_next(st);
 #endif
-#define ADMM_TET(K, MM) do { if (trk) hipLaunchKernelGGL((project_tet_kernel<K, MM, true>), grid, block, 0, st, d, x, tail, tail_block0); \
-                            else hipLaunchKernelGGL((project_tet_kernel<K, MM, false>), grid, block, 0, st, d, x, tail, tail_block0); } while (0)
+#define ADMM_TET(K, MM) do { if (trk) hipLaunchKernelGGL((project_tet_kernel<K, MM, true>), grid, block, ctx->tet_lds_pad, st, d, x, tail, tail_block0); \
+                            else hipLaunchKernelGGL((project_tet_kernel<K, MM, false>), grid, block, ctx->tet_lds_pad, st, d, x, tail, tail_block0); } while (0)
             if (max_lbfgs_iters(b) <= 5) ADMM_TET(0, 5); else ADMM_TET(0, 10);
             break;
         case ADMM_KIND_TET_STVK:
@@ -1838,7 +1847,7 @@ int ensure_residual_buffers(admm_hip_ctx *ctx, int iters) {
             // (ADMM_HIP_RES_UNFUSED=1: the separate passes, for comparison; not for pre-reduced tet batches, which have no per-corner slots)
             b.res_fused = ((b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK) || b.kind == ADMM_KIND_ANCHOR) && (b.prered || getenv("ADMM_HIP_RES_UNFUSED") == nullptr);
             if (b.res_fused) {      // the tet kernels produce their residuals themselves: no snapshots, one partial per 64-tet block
-                const int nblk = b.grp_blk.empty() ? (nl + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK : std::max(b.grp_blk.back(), 1);
+                const int nblk = std::max(batch_blocks(b), 1);
                 TRY(dalloc(ctx, &b.d_res_partial, (size_t)nblk));
                 HIPCHK(hipMemset(b.d_res_partial, 0, sizeof(double) * (size_t)nblk));
             } else { TRY(dalloc(ctx, &b.d_u_prev, (size_t)rows * nl)); TRY(dalloc(ctx, &b.d_z_prev, (size_t)rows * nl)); }
@@ -1913,7 +1922,7 @@ int launch_residuals(admm_hip_ctx *ctx, int it) {
     for (Batch &b : ctx->batches) {
         if (!b.n_local || b.kind == ADMM_KIND_GENERIC) continue;
         if (b.res_fused) {     // |r|^2 partials and the s slots were written by the projection kernel
-            const int nblk = b.grp_blk.empty() ? (b.n_local + LOCAL_BLOCK - 1) / LOCAL_BLOCK : b.grp_blk.back();
+            const int nblk = batch_blocks(b);
             hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RES_BLOCK), 0, ctx->stream, nblk, (const double *)b.d_res_partial, r2, first ? 0 : 1);
             first = false;
             continue;
@@ -2010,6 +2019,8 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_PIPE")) { const int v = atoi(g); if (v >= 2 && v <= 8) { ctx->pipe = v; ctx->groups = v; } }
     if (const char *g = getenv("ADMM_HIP_PRERED")) ctx->tet_prered = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_TET_LDS_PAD")) ctx->tet_lds_pad = std::max(0, atoi(g));
+    if (const char *g = getenv("ADMM_HIP_TPB")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ctx->tet_tpb = v; }
     if (const char *g = getenv("ADMM_HIP_KEEP_Z")) ctx->keep_z_user = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_CHAIN")) ctx->pipe_chain = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_PIPE_GRAPH")) ctx->pipe_graph = atoi(g) != 0;
@@ -2035,6 +2046,7 @@ void admm_hip_destroy(admm_hip_ctx *ctx) {
         for (double *h : {ctx->h_gen_dx, ctx->h_gen_u, ctx->h_gen_z, ctx->h_gen_q}) if (h) (void)hipHostFree(h);
         if (ctx->gen_ev) (void)hipEventDestroy(ctx->gen_ev);
         if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+        if (ctx->d_small) (void)hipFree(ctx->d_small);
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->state_in_ev) (void)hipEventDestroy(ctx->state_in_ev);
         for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
@@ -2219,11 +2231,11 @@ static unsigned long long *g_wave_t_buf; static size_t g_wave_t_n;
 extern "C" int admm_hip_debug_tet_wave_times(long n_waves, unsigned long long *out) {
     if (!out) {      // arm
         hipFree(g_wave_t_buf); g_wave_t_buf = nullptr; g_wave_t_n = (size_t)n_waves;
-        if (n_waves > 0 && hipMalloc(&g_wave_t_buf, 16 * g_wave_t_n) != hipSuccess) return ADMM_ERR_HIP;
-        if (n_waves > 0) hipMemset(g_wave_t_buf, 0, 16 * g_wave_t_n);
+        if (n_waves > 0 && hipMalloc(&g_wave_t_buf, 32 * g_wave_t_n) != hipSuccess) return ADMM_ERR_HIP;      // per wave: start, end, max evaluations, max iterations
+        if (n_waves > 0) hipMemset(g_wave_t_buf, 0, 32 * g_wave_t_n);
         return hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_tet_wave_t), &g_wave_t_buf, sizeof(g_wave_t_buf)) == hipSuccess ? ADMM_OK : ADMM_ERR_HIP;
     }
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, g_wave_t_buf, 16 * g_wave_t_n, hipMemcpyDeviceToHost) != hipSuccess) return ADMM_ERR_HIP;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, g_wave_t_buf, 32 * g_wave_t_n, hipMemcpyDeviceToHost) != hipSuccess) return ADMM_ERR_HIP;
     return ADMM_OK;
 }
 #endif
@@ -2270,12 +2282,7 @@ static int host_allreduce_trampoline(void *self, void *dev_buf, int64_t count, v
     if (!ctx->host_allreduce) return 1;
     if ((size_t)count > ctx->h_comm_cap) {
         (void)hipStreamSynchronize(st);      // the previous call's host-to-device copy may still be reading the old staging buffer
-        if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
-        for (hipStream_t st : ctx->pipe_local_streams) (void)hipStreamDestroy(st);
-        for (hipEvent_t e : ctx->pipe_ev_fwd) (void)hipEventDestroy(e);
-        for (hipEvent_t e : ctx->pipe_ev_tet) (void)hipEventDestroy(e);
-        for (hipEvent_t e : ctx->pipe_ev_sw) (void)hipEventDestroy(e);
-        if (ctx->pipe_ev_top) (void)hipEventDestroy(ctx->pipe_ev_top);
+        if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);      // (only the staging buffer: every stream / event of the context belongs to admm_hip_destroy)
         ctx->h_comm = nullptr; ctx->h_comm_cap = 0;
         if (hipHostMalloc((void **)&ctx->h_comm, sizeof(double) * (size_t)count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
         ctx->h_comm_cap = (size_t)count;
@@ -2332,6 +2339,26 @@ int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count) {
     if (!ctx || ctx->device_id < 0 || !dev_buf || count < 0) return ADMM_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device_id));
     TRY(do_allreduce(ctx, (double *)dev_buf, count));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ADMM_OK;
+}
+
+// a small HOST vector summed across the ranks through the transport the iterations use (the class mirror: the released
+// MovingAnchors' positions, owner's values + zeros elsewhere); world 1: nothing to do
+int admm_hip_allreduce_host(admm_hip_ctx *ctx, double *host_buf, int64_t count) {
+    if (!ctx || ctx->device_id < 0 || !host_buf || count < 0) return ADMM_ERR_ARG;
+    if (ctx->world <= 1 || count == 0) return ADMM_OK;
+    HIPCHK(hipSetDevice(ctx->device_id));
+    if ((size_t)count > ctx->d_small_cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_small) (void)hipFree(ctx->d_small);
+        ctx->d_small = nullptr; ctx->d_small_cap = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_small, sizeof(double) * (size_t)count));
+        ctx->d_small_cap = (size_t)count;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_small, host_buf, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    TRY(do_allreduce(ctx, ctx->d_small, count));
+    HIPCHK(hipMemcpyAsync(host_buf, ctx->d_small, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ADMM_OK;
 }

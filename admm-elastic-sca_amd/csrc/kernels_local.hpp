@@ -38,6 +38,9 @@ namespace admm_dev {
 #define ADMM_LOCAL_BLOCK 64
 #endif
 constexpr int LOCAL_BLOCK = ADMM_LOCAL_BLOCK;
+// one wave per workgroup is built in: the tet kernels' block-level RHS pre-reduction keeps one byte per corner position (pos4),
+// a 256-entry LDS staging per block, and s_waitcnt in place of a workgroup barrier; track_block_sum is a wave butterfly
+static_assert(LOCAL_BLOCK == 64, "the local-step kernels assume one 64-lane wave per workgroup");
 #ifndef ADMM_TET_WAVES
 #define ADMM_TET_WAVES 2   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
 #endif
@@ -69,6 +72,7 @@ struct BatchDev {
     const unsigned short *bn_end;    // [entries] end of the node's run in the staging (its start = the previous entry's end, 0 for the first)
     double *res_slots;     // residual tracking fused into the tet kernels (TRACK): per-corner shares of s = D^T W^T W (z - z_prev), same slot layout as fslot
     double *res_partial;   // ... and per 64-tet block: sum of w^2 |u_new - u_old|^2 (the block's part of |r|^2)
+    int tpb;               // tets: elements per one-wave block (64; fewer in under-filled launches, the lanes beyond idle)
     const int *order;      // tets, large batches: which 64-tet block workgroup i processes (costliest blocks of the last frame first), or NULL
     unsigned int *cost;    // [blocks]: real-time ticks every block took, summed over a frame (feeds `order`), or NULL
 };
@@ -229,14 +233,14 @@ __device__ __forceinline__ void project_tet_block(const BatchDev &b, const doubl
     // that took longest in the last frame start first (order_by_cost_kernel, once per frame); results do not depend on the order.
     const int blk = b.order ? b.order[lb] : lb;
     const unsigned long long t_begin = b.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int e = b.e0 + blk * LOCAL_BLOCK + threadIdx.x;
+    const int e = b.e0 + blk * b.tpb + threadIdx.x;
     const int n = b.n;
-    if (e >= b.e1) return;
+    if ((int)threadIdx.x >= b.tpb || e >= b.e1) return;
     double B[12];
     Mat3 Dx, u, F, z;
     Mat3 zp;      // TRACK: z of the previous iteration
     ADMM_PROF_T0
-    ADMM_TET_STAMP(e, 0);
+    ADMM_TET_STAMP(lb, 0, __builtin_amdgcn_s_memrealtime());
     tet_load(b, x, e, n, B, Dx, u);
     F = mat_add(Dx, u);
     ADMM_PROF_TIME(0);
@@ -264,6 +268,9 @@ __device__ __forceinline__ void project_tet_block(const BatchDev &b, const doubl
         st_stream(&b.state[(size_t)0 * n + e], sa); st_stream(&b.state[(size_t)1 * n + e], sb); st_stream(&b.state[(size_t)2 * n + e], sc); st_stream(&b.state[(size_t)3 * n + e], hs);
 #else
         b.state[(size_t)0 * n + e] = sa; b.state[(size_t)1 * n + e] = sb; b.state[(size_t)2 * n + e] = sc; b.state[(size_t)3 * n + e] = hs;
+#endif
+#if ADMM_NFEV_COUNT
+        ADMM_TET_STAMP_MAX(lb, 2, it >> 8); it &= 255; ADMM_TET_STAMP_MAX(lb, 3, it);
 #endif
         if (TRACK || b.keep_z) b.n_iters[e] = it;      // (an introspection output like z: admm_hip_read_local's n_iters)
     } else {
@@ -360,7 +367,7 @@ __device__ __forceinline__ void project_tet_block(const BatchDev &b, const doubl
 #if ADMM_PROF_ON
     if (threadIdx.x == 0) atomicAdd(&admm_dev::g_tet_prof[16], 1ull);
 #endif
-    ADMM_TET_STAMP(e, 1);
+    ADMM_TET_STAMP(lb, 1, __builtin_amdgcn_s_memrealtime());
     if (b.cost && threadIdx.x == 0) b.cost[blk] += (unsigned int)(__builtin_amdgcn_s_memrealtime() - t_begin);
 }
 
@@ -524,15 +531,10 @@ __device__ __forceinline__ void project_bend_block(const BatchDev &b, const doub
 }
 
 // ---------------------------------------------------------------------------
-// LimitedTriangleStrain, TriangleForce.cpp:78-113.
-// T = U(:,0:2) V^T of the 3x2 SVD is the polar factor of F; computed here
-// through the 2x2 symmetric eigen-decomposition of F^T F (closed form), which
-// agrees with the reference's QR-preconditioned Jacobi SVD to rounding
-// (tests state the tolerance; this kernel is not bit-exact by construction).
+// Triangles, TriangleForce.cpp.  MODE 0: LimitedTriangleStrain (:78-113), T = U(:,0:2) V^T of the 3x2 SVD, blended and
+// strain-limited; MODE 1: TriArea (:251-295); MODE 2: FungTriangle (:227-249).  All three run the bit-exact restatement of
+// Eigen's JacobiSVD<3x2> (column-pivoted Householder QR + 2x2 Jacobi, local_math.hpp svd32): bit-identical with the reference.
 // ---------------------------------------------------------------------------
-// MODE 0: LimitedTriangleStrain (above).  MODE 1: TriArea (TriangleForce.cpp:251-295) and MODE 2:
-// FungTriangle (:227-249) need the singular values and vectors themselves: they run the bit-exact
-// restatement of Eigen's 3x2 JacobiSVD (local_math.hpp svd32).
 template <int MODE>
 __device__ __forceinline__ void project_tri_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
     const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;

@@ -18,7 +18,7 @@
 
 #include "log_glibc_data.hpp"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ADMM_HD __host__ __device__ __forceinline__
 #else
 #define ADMM_HD inline
@@ -31,12 +31,24 @@
 namespace admm_dev {
 
 // ---- wave timeline of the tet kernel (tools/probe/tet_timeline.py; build flag -DADMM_TET_TIMELINE, never on in the shipped library):
-// the first lane of every wave stamps the 100 MHz real-time counter at its start and at its end -- nothing else is added
+// the first lane of every wave stamps the 100 MHz real-time counter at its start and at its end, and the wave's largest per-lane
+// count of line-search evaluations and L-BFGS iterations -- four words per one-wave block of the launch
 #if defined(ADMM_TET_TIMELINE) && defined(__HIPCC__)
 __device__ unsigned long long *g_tet_wave_t;
-#define ADMM_TET_STAMP(e, slot) do { if (admm_dev::g_tet_wave_t && (threadIdx.x & 63) == 0) admm_dev::g_tet_wave_t[2 * (size_t)((e) >> 6) + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#if defined(ADMM_TET_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
+#define ADMM_NFEV_COUNT 1
+__device__ __forceinline__ unsigned long long wave_max_u(int v) {
+    const unsigned long long act = __ballot(1);      // (lanes beyond the batch / the block's tets have left: their registers are not read)
+    for (int o = 32; o; o >>= 1) { const int other = __shfl_xor(v, o); if (((act >> ((threadIdx.x & 63) ^ o)) & 1ull) && other > v) v = other; }
+    return (unsigned long long)v;
+}
+#define ADMM_TET_STAMP(w, slot, val) do { if (admm_dev::g_tet_wave_t && (threadIdx.x & 63) == 0) admm_dev::g_tet_wave_t[4 * (size_t)(w) + (slot)] = (val); } while (0)
+#define ADMM_TET_STAMP_MAX(w, slot, v) do { const unsigned long long m_ = admm_dev::wave_max_u(v); ADMM_TET_STAMP(w, slot, m_); } while (0)
 #else
-#define ADMM_TET_STAMP(e, slot)
+#define ADMM_NFEV_COUNT 0
+#define ADMM_TET_STAMP(w, slot, val)
+#define ADMM_TET_STAMP_MAX(w, slot, v)
 #endif
 
 // ---- phase attribution of the tet kernel (tools/tet_phase_profile.py; build flag -DADMM_TET_PROFILE, never on in the
@@ -383,7 +395,7 @@ ADMM_HD double admm_exp(double x) {
 template <int TYPE> struct Prox {
     double mu, lambda, k;
     V3 s0;
-#if ADMM_PROF_ON
+#if ADMM_PROF_ON || ADMM_NFEV_COUNT
     mutable int prof_nfev = 0;
 #endif
 
@@ -556,7 +568,7 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         g = prob.gradient(xn);
         g_out = g; evaluated = true;
         nfev++;
-#if ADMM_PROF_ON
+#if ADMM_PROF_ON || ADMM_NFEV_COUNT
         prob.prof_nfev++;
 #endif
         double dg = dotd(g, s);
@@ -696,6 +708,9 @@ ADMM_HD Mat3 project_hyper(const Mat3 &F, double mu, double lambda, int maxIter,
     const double prof_g0 = absmax(P.gradient(x2));
 #endif
     n_iters = lbfgs_minimize<M>(P, x2, maxIter, 1e-8, hess);
+#if ADMM_NFEV_COUNT
+    n_iters += 256 * P.prof_nfev;      // (timeline build only: the lane's evaluation count rides out in the upper bits, project_tet_block splits it off)
+#endif
     sa = x2.a; sb = x2.b; sc = x2.c;
     mid();
     ADMM_PROF_TIME(2);
@@ -897,7 +912,7 @@ ADMM_HD void project_triarea_p(const double d[6], int iters, double lmin, double
 // (every reduction in the L-BFGS / line search is (a + b) + c, so the zero third component leaves
 // the arithmetic of the 2-variable solver untouched)
 struct FungProx {
-#if ADMM_PROF_ON
+#if ADMM_PROF_ON || ADMM_NFEV_COUNT
     mutable int prof_nfev = 0;
 #endif
     double mu, k;

@@ -89,7 +89,7 @@ public:
         // (admm_hip_set_host_allreduce, e.g. comm::ShmAllReduce::hook) in place across the ranks
         admm_hip_allreduce_fn allreduce; void *allreduce_user;
         admm_hip_host_allreduce_fn host_allreduce; void *host_allreduce_user;
-        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(120.0), rendezvous_max_age_s(600.0),
+        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(120.0), rendezvous_max_age_s(120.0),
                   allreduce(nullptr), allreduce_user(nullptr), host_allreduce(nullptr), host_allreduce_user(nullptr) {}
         // what a launcher exports: torchrun / torch.distributed.run (RANK, WORLD_SIZE, LOCAL_RANK), Open MPI, Slurm;
         // ADMM_HIP_RCCL_ID_FILE names the rendezvous file.  Returns the local rank (the caller's device_id), or -1 if no launcher is seen.
@@ -101,9 +101,13 @@ public:
                 if (!r || !w) continue;
                 rank = std::atoi(r); world = std::atoi(w);
                 if (const char *f = std::getenv("ADMM_HIP_RCCL_ID_FILE")) rccl_id_file = f;
-                else if (rccl_id_file.empty()) {      // per job: the launcher's rendezvous port / job id tells two jobs on one node apart
+                else if (rccl_id_file.empty()) {
+                    // per launch: the launcher's rendezvous port / job id tells two jobs on one node apart (and Comm.hpp's launch_nonce(), stored in the
+                    // file, a crashed earlier launch's leftover).  Nothing job-unique in the environment: the name stays empty and initialize()
+                    // fails with a message that asks for ADMM_HIP_RCCL_ID_FILE -- never a name two jobs could share.
                     const char *tag = std::getenv("MASTER_PORT"); if (!tag) tag = std::getenv("SLURM_JOB_ID"); if (!tag) tag = std::getenv("OMPI_MCA_ess_base_jobid");
-                    rccl_id_file = std::string("/tmp/admm_hip_rccl_id.") + std::to_string((long)getuid()) + "." + (tag ? tag : "0");
+                    if (!tag) tag = std::getenv("PMIX_NAMESPACE");
+                    if (tag) rccl_id_file = std::string("/tmp/admm_hip_rccl_id.") + std::to_string((long)getuid()) + "." + tag;
                 }
                 return l ? std::atoi(l) : rank;
             }
@@ -279,12 +283,21 @@ public:
             for (int e = 0; e < batch_count[b] && !any_released; ++e) any_released = !static_cast<MovingAnchor *>(forces[batch_first[b] + e].get())->point->active;
             if (!any_released) continue;
             if (shard.world > 1) {
-                // sharded: a rank holds the projection state of its own anchors only; every rank takes the node's position
-                // after the frame instead (the value the next frame's first Dx would give), so the control points stay
-                // identical on all ranks
+                // sharded: a rank holds the projection state of its own anchors only.  The owner's Dx of the last project() (the
+                // reference's value, AnchorForce.cpp:80-83) + zeros elsewhere, summed over the ranks through the iterations' own
+                // transport: the control points are the single-GPU run's on every rank
+                std::vector<double> &all = anchor_tgt;
+                all.assign((size_t)batch_count[b] * 3, 0.0);
+                anchor_ids.resize((size_t)batch_count[b]);
+                int n_local = 0;
+                if (!check(admm_hip_local_elements(gpu, (int)b, anchor_ids.data(), batch_count[b], &n_local))) return false;
+                anchor_loc.resize((size_t)(n_local > 0 ? n_local : 1) * 3);
+                if (n_local > 0 && !check(admm_hip_read_local(gpu, (int)b, nullptr, nullptr, anchor_loc.data(), nullptr))) return false;
+                for (int l = 0; l < n_local; ++l) for (int c = 0; c < 3; ++c) all[3 * (size_t)anchor_ids[l] + c] = anchor_loc[3 * (size_t)l + c];
+                if (!check(admm_hip_allreduce_host(gpu, all.data(), (int64_t)all.size()))) return false;
                 for (int e = 0; e < batch_count[b]; ++e) {
                     MovingAnchor *ma = static_cast<MovingAnchor *>(forces[batch_first[b] + e].get());
-                    if (!ma->point->active) for (int c = 0; c < 3; ++c) ma->point->pos[c] = m_x[3 * (size_t)ma->idx + c];
+                    if (!ma->point->active) for (int c = 0; c < 3; ++c) ma->point->pos[c] = all[3 * (size_t)e + c];
                 }
                 continue;
             }
@@ -334,7 +347,7 @@ protected:
     std::vector<int> user_local;
     VectorXd user_Dx, user_u, user_z;
     void *pinned_x, *pinned_v, *seen_x, *seen_v; size_t pinned_bytes;
-    std::vector<double> anchor_tgt; std::vector<int32_t> anchor_act;     // step(): this frame's control points
+    std::vector<double> anchor_tgt, anchor_loc; std::vector<int32_t> anchor_act, anchor_ids;     // step(): this frame's control points
     int init_count;                        // initialize() calls so far (every rank counts alike: part of the rendezvous file's name)
 
     // world > 1: hand rank / world / mode to the library and install the all-reduce -- a caller's hook, or (default) an RCCL
@@ -352,7 +365,7 @@ protected:
         const std::string file = shard.rccl_id_file.empty() ? std::string() : shard.rccl_id_file + "." + std::to_string(init_count);
         std::string why;
         if (!comm::rccl_id_via_file(file, shard.rank, id, shard.rendezvous_timeout_s, shard.rendezvous_max_age_s, &why)) {
-            std::cerr << "\n**Solver Error: multi-GPU rendezvous failed: " << why << " (set System::shard.rccl_id_file, or install an all-reduce hook)" << std::endl;
+            std::cerr << "\n**Solver Error: multi-GPU rendezvous failed: " << why << " (set System::shard.rccl_id_file / ADMM_HIP_RCCL_ID_FILE to a path unique to this launch, or install an all-reduce hook)" << std::endl;
             return false;
         }
         const bool ok = check(admm_hip_rccl_init(gpu, id, shard.rank, shard.world));     // collective: returns once every rank has joined

@@ -145,6 +145,10 @@ int admm_hip_rccl_unique_id(void *id128);
 int admm_hip_rccl_init(admm_hip_ctx *ctx, const void *id128, int rank, int world);
 int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm);
 int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count);
+/* A short HOST vector summed in place across the ranks through the same transport (no-op at world 1).  The class mirror uses
+ * it for what the reference keeps per force object and a sharded run keeps on the owner rank only: a released MovingAnchor's
+ * position, point->pos = Dx of the last project() (AnchorForce.cpp:80-83) -- owner's value, zeros elsewhere.              */
+int admm_hip_allreduce_host(admm_hip_ctx *ctx, double *host_buf, int64_t count);
 /* How the work is split across the ranks (before finalize; env ADMM_HIP_SHARD=contiguous|subtree overrides):
  *   ADMM_SHARD_CONTIGUOUS  every batch is cut into `world` contiguous element ranges; per ADMM iteration the whole right-hand
  *                          side (3 n doubles) is all-reduced and every rank runs the complete solve.

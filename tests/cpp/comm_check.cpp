@@ -2,6 +2,7 @@
 // segment's capacity) and the rendezvous file for the RCCL id.
 // usage: comm_check shm <name> <rank> <world> <count> <capacity>   -> prints "ok <checksum>"
 //        comm_check file <path> <rank> [max_age_s]                 -> rank 0 publishes 128 known bytes, others print what they read
+//        comm_check reopen <name> <rank> <world>                   -> open / all-reduce / close / open again on the SAME object (the barrier's sense starts over)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,20 @@ int main(int argc, char **argv) {
             }
         }
         printf("ok %.17g\n", sum);
+        return 0;
+    }
+    if (argc >= 5 && !strcmp(argv[1], "reopen")) {
+        const int rank = atoi(argv[3]), world = atoi(argv[4]);
+        comm::ShmAllReduce shm;
+        double v[3];
+        for (int pass = 0; pass < 3; ++pass) {      // an odd number of barriers per pass (1 in open + 2 per all-reduce) leaves sense_ at 1: the next open must reset it
+            if (!shm.open(std::string(argv[2]) + (char)('a' + pass), rank, world, 64, 20.0)) { fprintf(stderr, "rank %d: open %d failed\n", rank, pass); return 2; }
+            for (int i = 0; i < 3; ++i) v[i] = rank + 1.0 + i + pass;
+            if (!shm.allreduce(v, 3)) return 3;
+            for (int i = 0; i < 3; ++i) { double e = 0; for (int r = 0; r < world; ++r) e += r + 1.0 + i + pass; if (v[i] != e) { fprintf(stderr, "rank %d pass %d: %g != %g\n", rank, pass, v[i], e); return 4; } }
+            shm.close();
+        }
+        printf("ok\n");
         return 0;
     }
     if (argc >= 4 && !strcmp(argv[1], "file")) {

@@ -4,6 +4,7 @@ sample programs and a ForceBuilder-style scene, compiled with g++ against the
 mirror and libadmm_hip.so.  CPU: they compile, link and fail loudly without a
 GPU.  GPU: known answers and parity with the oracle."""
 import os
+import time
 import struct
 import subprocess
 
@@ -119,6 +120,8 @@ def test_shard_from_env(pkg):
     assert out.startswith("local 3 rank 3 world 8 file /tmp/admm_hip_rccl_id.") and out.endswith(".29511")
     assert run(OMPI_COMM_WORLD_RANK="5", OMPI_COMM_WORLD_SIZE="16", OMPI_COMM_WORLD_LOCAL_RANK="1", ADMM_HIP_RCCL_ID_FILE="/shared/job7.id") == "local 1 rank 5 world 16 file /shared/job7.id"
     assert run(SLURM_PROCID="2", SLURM_NTASKS="4", SLURM_LOCALID="2", SLURM_JOB_ID="991").endswith(".991")
+    # nothing job-unique in the environment: no default name two jobs could share (initialize() then asks for ADMM_HIP_RCCL_ID_FILE)
+    assert run(RANK="1", WORLD_SIZE="2", LOCAL_RANK="1") == "local 1 rank 1 world 2 file"
 
 
 def test_comm_helpers_on_the_cpu(pkg, tmp_path):
@@ -139,6 +142,34 @@ def test_comm_helpers_on_the_cpu(pkg, tmp_path):
     os.utime(idf, (old, old))                                                                    # a leftover of an earlier job
     stale = subprocess.run([exe, "file", idf, "1", "600"], capture_output=True, text=True, timeout=60)
     assert stale.returncode == 5 and "timed out" in stale.stdout
+    # the id of ANOTHER launch (other port -> other nonce in the file) is not taken, however fresh
+    idf2 = str(tmp_path / "rccl_id2")
+    env_a, env_b = dict(os.environ, MASTER_PORT="29611"), dict(os.environ, MASTER_PORT="29612")
+    assert subprocess.run([exe, "file", idf2, "0"], capture_output=True, text=True, timeout=60, env=env_a).returncode == 0
+    other = subprocess.run([exe, "file", idf2, "1"], capture_output=True, text=True, timeout=60, env=env_b)
+    assert other.returncode == 5 and "timed out" in other.stdout
+    assert subprocess.run([exe, "file", idf2, "1"], capture_output=True, text=True, timeout=60, env=env_a).stdout.startswith("ok ")
+    # a symlink under the name is not followed by the reader, and rank 0 replaces it instead of writing through it
+    victim = tmp_path / "victim"; victim.write_bytes(b"x" * 144)
+    idf3 = str(tmp_path / "rccl_id3"); os.symlink(str(victim), idf3)
+    assert subprocess.run([exe, "file", idf3, "1"], capture_output=True, text=True, timeout=60).returncode == 5
+    assert subprocess.run([exe, "file", idf3, "0"], capture_output=True, text=True, timeout=60).returncode == 0
+    assert victim.read_bytes() == b"x" * 144 and not os.path.islink(idf3) and oct(os.stat(idf3).st_mode & 0o777) == "0o600"
+    # the same ShmAllReduce object opened again after close(): the barrier's sense starts over
+    ps = [subprocess.Popen([exe, "reopen", name + "_re", str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    # a crashed run's segment left under the name: a rank that attaches to it before rank 0 has replaced it finds its way to the new one
+    import mmap, struct
+    seg = "/dev/shm" + name + "_stale"
+    nbytes = 64 + 8 * 1024 * 2
+    with open(seg, "wb") as f:
+        f.write(struct.pack("<IiiiI", 0xADB17E55, 0, 0, 0, 2).ljust(64, b"\0")); f.truncate(nbytes)
+    late = subprocess.Popen([exe, "shm", name + "_stale", "1", "2", "100", "1024"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(0.5)                                                                              # rank 1 now sits on the orphan's barrier
+    first = subprocess.Popen([exe, "shm", name + "_stale", "0", "2", "100", "1024"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o0, o1 = first.communicate(timeout=120), late.communicate(timeout=120)
+    assert first.returncode == 0 and late.returncode == 0 and o0[0] == o1[0], (o0, o1)
 
 
 @pytest.mark.gpu
@@ -186,11 +217,12 @@ def test_scene_through_class_api_multi_rank(pkg, tmp_path, world, mode):
     assert np.abs(Xw[0] - X1[0]).max() < 1e-11
     # ten iterations per frame, five frames: the truncated StVK prox amplifies last-bit differences of its input (the reference
     # against itself from a 1-ulp perturbed start: 2e-6 after one frame); the released control point (frames 3, 4)
-    # follows the node on every rank
+    # is the reference's value on every rank -- Dx of the last project() (AnchorForce.cpp:80-83), i.e. the node BEFORE the last
+    # global solve: the owner rank's state travels through admm_hip_allreduce_host
     (X1, cp1), (Xw, cpw) = run(5, 10, "b")
     assert np.abs(Xw - X1).max() < 2e-5
-    assert np.abs(cpw - Xw[-1][3 * moving:3 * moving + 3]).max() == 0.0
-    assert np.abs(cpw - cp1).max() < 1e-3           # (single rank: Dx of the last iteration; sharded: the node after the frame)
+    assert np.abs(cpw - cp1).max() < 2e-5
+    assert 0.0 < np.abs(cp1 - X1[-1][3 * moving:3 * moving + 3]).max() < 1e-2      # (not the node after the frame)
 
 
 @pytest.mark.gpu
