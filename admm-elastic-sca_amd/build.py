@@ -80,5 +80,17 @@ def _build_locked(force, verbose, extra_hip_flags, out, tag):
     return out
 
 
+def source_hash():
+    """sha256 over the library's sources (csrc/*, include/*.h): stamps counter files (tools/pmc_collect.sh) so that bench.py can tell
+    whether the committed PMC summary was collected on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".hip", ".cpp")))
+    files += [os.path.join(HERE, "..", "include", f) for f in ("admm_hip.h", "admm_kinds.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

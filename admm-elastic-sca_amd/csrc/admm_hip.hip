@@ -159,7 +159,7 @@ struct admm_hip_ctx {
     // and residual tracking always store it.  ADMM_HIP_KEEP_Z=0 / 1 overrides.
     bool keep_z = true, keep_z_user = true;
     int tet_lds_pad = 0;                      // ADMM_HIP_TET_LDS_PAD (probes only): unused dynamic LDS per tet block, caps the waves per SIMD (160 KB per CU)
-    int tet_tpb = 0;                          // ADMM_HIP_TPB: tets per one-wave block (8 / 16 / 32 / 64); 0 = chosen per batch from its size (upload_all)
+    int tet_tpb = 0;                          // ADMM_HIP_TPB: tets per one-wave block (4 / 8 / 16 / 32 / 64) for the NH / StVK batches; 0 = 64
     bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
     int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
     std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
@@ -1178,7 +1178,14 @@ int upload_all(admm_hip_ctx *ctx) {
         b.corner_perm.assign((size_t)b.n_total * nn, 0);
         b.prered = ctx->tet_prered && b.kind >= ADMM_KIND_TET_LINEAR && b.kind <= ADMM_KIND_TET_STVK;
         b.tpb = admm_dev::LOCAL_BLOCK;
-        if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && b.grp_ptr.empty() && ctx->tet_tpb > 0) b.tpb = ctx->tet_tpb;
+        if ((b.kind == ADMM_KIND_TET_NH || b.kind == ADMM_KIND_TET_STVK) && b.grp_ptr.empty()) {
+            // Fewer tets per one-wave block (the lanes beyond idle) shortens the union of paths a wave executes.  Measured (profiles/r04/underfilled.txt):
+            // it pays only where the launch is under-filled AND ends in a long tail of a few pathological tets -- BASELINE configs[2] (50 700 StVK tets)
+            // at frame 14: local step 136 -> 126 us (32 per block) -> 120 us (16); the same bar at frame 8: 78 -> 76 -> 92 us; Neo-Hookean bars of
+            // 5 400 / 18 000 / 50 700 / 125 000 tets: 42 -> 47, 69 -> 72, 73 -> 75, 84 -> 98 us with 32 per block.  No size rule separates the cases
+            // (the tail comes and goes with the deformation), so the default stays 64; ADMM_HIP_TPB sets it by hand.
+            if (ctx->tet_tpb > 0) b.tpb = ctx->tet_tpb;
+        }
         std::vector<int> blk_nodes;       // prered: the nodes of the current 64-tet block
         for (int el = 0; el < b.n_local; ++el) {
             const int e = b.local[el];

@@ -141,6 +141,53 @@ template <int P, int Q> ADMM_HD void rot_cols(Mat3 &m, double c, double s) {
     rot2(at<2, P>(m), at<2, Q>(m), c, s);
 }
 
+// ---- correctly rounded sqrt and reciprocal for arguments whose RANGE is known ------------------------------------------
+// hipcc expands an fp64 sqrt into v_rsq_f64 + two coupled Newton steps (correctly rounded), wrapped in a rescaling of
+// arguments below 2^-767 and a pass-through of 0 / +inf; an fp64 division into v_rcp_f64 + two Newton steps + one correction,
+// wrapped in v_div_scale (x2), v_div_fmas and v_div_fixup for operands near the ends of the exponent range and for 0 / inf / nan.
+// Where the argument provably lies in [1, 4) resp. [1, 2) the wrappers select nothing and the unscaled core produces the
+// very same bits: the Jacobi rotation's sqrt(1 + (q/p)^2), sqrt(tau^2 + 1), sqrt(t^2 + 1) and 1 / sqrt(t^2 + 1)
+// (EIG/Jacobi/Jacobi.h:80-110, EIG/Core/MathFunctions.h:284-302) drop 25 of their ~295 instructions per rotation -- the tet kernels
+// sit on the VALU issue roof (profiles/r04/valu_roof.txt), so instructions are time.  A NaN argument comes out as NaN either way.
+// Host builds (tests/host_math_shim.cpp) keep libm's sqrt and the plain division: both are correctly rounded, i.e. the same bits.
+ADMM_HD double sqrt_core(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+#else
+    return sqrt(x);
+#endif
+}
+ADMM_HD double sqrt_in_1_4(double x) { return sqrt_core(x); }                                  // x in [1, 4) (or NaN)
+ADMM_HD double sqrt_ge_1(double x) {                                                           // x in [1, +inf] (or NaN)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double g = sqrt_core(x);
+    return x == __builtin_inf() ? x : g;
+#else
+    return sqrt(x);
+#endif
+}
+ADMM_HD double rcp_in_1_2(double b) {                                                          // 1.0 / b for b in [1, 2) (or NaN)
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double r = __builtin_fma(-b, y, 1.0);      // (the quotient's first estimate 1.0 * y is y itself)
+    return __builtin_fma(r, y, y);
+#else
+    return 1.0 / b;
+#endif
+}
+
 // numext::hypot, EIG/Core/MathFunctions.h:284-302
 ADMM_HD double eig_hypot(double x, double y) {
     double ax = fabs(x), ay = fabs(y);
@@ -148,7 +195,7 @@ ADMM_HD double eig_hypot(double x, double y) {
     if (p == 0.0) return 0.0;
     double q = smin(ax, ay);
     double qp = q / p;
-    return p * sqrt(1.0 + qp * qp);
+    return p * sqrt_in_1_4(1.0 + qp * qp);      // q <= p: the argument lies in [1, 2]
 }
 
 // One (p,q) step of the two-sided Jacobi sweep: threshold test,
@@ -176,10 +223,10 @@ template <int P, int Q> ADMM_HD bool jacobi_pq(Mat3 &W, Mat3 &U, Mat3 &V) {
     if (m01 == 0.0) { rc = 1.0; rs = 0.0; }
     else {
         double tau = (m00 - m11) / (2.0 * fabs(m01));
-        double w = sqrt(tau * tau + 1.0);
-        double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double w = sqrt_ge_1(tau * tau + 1.0);
+        double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);      // |tau +- w| >= 1: |tt| <= 1
         double sign_t = tt > 0.0 ? 1.0 : -1.0;
-        double n = 1.0 / sqrt(tt * tt + 1.0);
+        double n = rcp_in_1_2(sqrt_in_1_4(tt * tt + 1.0));                // the argument lies in [1, 2], its root in [1, 1.42]
         rs = -sign_t * unit_sign(m01) * fabs(tt) * n;
         rc = n;
     }
@@ -844,10 +891,10 @@ ADMM_HD void svd32(const double F[6], double U2[6], double &s0, double &s1, doub
             if (m01 == 0.0) { rc = 1.0; rs = 0.0; }
             else {
                 const double tau = (m00 - m11) / (2.0 * fabs(m01));
-                const double w = sqrt(tau * tau + 1.0);
+                const double w = sqrt_ge_1(tau * tau + 1.0);
                 const double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
                 const double sign_t = tt > 0.0 ? 1.0 : -1.0;
-                const double n = 1.0 / sqrt(tt * tt + 1.0);
+                const double n = rcp_in_1_2(sqrt_in_1_4(tt * tt + 1.0));
                 rs = -sign_t * unit_sign(m01) * fabs(tt) * n;
                 rc = n;
             }

@@ -36,7 +36,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured achievable)
-VALU_ISSUE_SLOTS_PER_S = 1024 * 2.4e9 / 4.0   # 256 CUs x 4 SIMDs at 2.4 GHz; one wave-wide VALU instruction occupies a SIMD for 4 cycles (fp64 FMA: more)
+VALU_ISSUE_SLOTS_PER_S = 1024 * 2.4e9 / 4.0   # NOMINAL: 256 CUs x 4 SIMDs at 2.4 GHz; one wave-wide VALU instruction occupies a SIMD for 4 cycles
+# MEASURED on this part (tools/probe/valu_throughput.hip, profiles/r04/valu_roof.txt): with every SIMD of the chip saturated (8 waves of
+# dependent fp64 chains each) a SIMD retires one wave-wide fp64 add / mul / fma / max / ldexp / compare / select per 2.00-2.15 ns -- 4 cycles at
+# the ~2.0 GHz the chip sustains under fp64 load, not at 2.4 GHz -- and one v_rcp_f64 / v_rsq_f64 per 6.9 ns.  The floor below prices the
+# launch's instruction counts (PMC) at the FASTEST measured rates.
+VALU_NS_PER_INST_MEASURED = 2.00
+VALU_NS_PER_TRANS_MEASURED = 6.92
 RHS_BYTES_PER_NODE = 48.0      # rhs_gather_kernel: M x_bar read and b written per node (+ the slots, counted from info.rhs_slots)
 # SURVEY.md section 8(d) prices the tet kernel at 472 B per tet and ADMM iteration (read 296 B + write 176 B) and the RHS assembly at
 # 96 B per tet + 48 B per node: these ALGORITHMIC figures are the yardstick of roofline.achieved / frac (the contract's definition).
@@ -97,22 +103,18 @@ def cpu_baseline(dims):
     getter = getattr(lib, ("ref_" if kind == "reference" else "orc_") + "omp_threads")
     hw = os.cpu_count() or 1
     tried = {}
-    teams = sorted({t for t in (16, 64, getter(), hw) if 1 <= t <= hw}) if setter is not None else [getter()]
-    frames = 1 if len(teams) > 1 else 2
-    for team in teams:
+    teams = sorted({t for t in (16, 32, 64, getter(), hw) if 1 <= t <= hw}) if setter is not None else [getter()]
+    frames = 1
+    for team in teams:          # two single frames per team size, the faster one counts: the baseline at its best
         if setter is not None:
             setter(int(team))
-        tried[int(team)] = s.time_steps(frames) / frames
+        tried[int(team)] = min(s.time_steps(1), s.time_steps(1))
     cores = min(tried, key=tried.get)
-    if len(teams) > 1:        # the scan is one frame per team size: time the winner again over two more frames and report THAT
-        setter(int(cores))
-        frames = 2
-        tried[cores] = s.time_steps(frames) / frames
     sec = tried[cores] * frames
     val = frames * ADMM_ITERS / sec * tets.shape[0]
     out = {"value": val, "unit": "ADMM iters/s x elements", "cores": int(cores), "kind": kind,
-           "sample": "NH bar %dx%dx%d cubes = %d tets; 1 warm-up frame, one frame per OpenMP team size to find the best, then %d frames x %d ADMM iters with that team (reported); initialize() %.1f s excluded; "
-                     "%.1f ms/iter" % (nx, ny, nz, tets.shape[0], frames, ADMM_ITERS, t_init, 1e3 * sec / (frames * ADMM_ITERS)),
+           "sample": "NH bar %dx%dx%d cubes = %d tets; 1 warm-up frame, then two frames of %d ADMM iters per OpenMP team size (%s threads), the fastest frame of the fastest team reported; initialize() %.1f s excluded; "
+                     "%.1f ms/iter" % (nx, ny, nz, tets.shape[0], ADMM_ITERS, " / ".join(str(t) for t in teams), t_init, 1e3 * sec / (frames * ADMM_ITERS)),
            "ms_per_iter": 1e3 * sec / (frames * ADMM_ITERS), "cpu_model": _cpu_model(), "hardware_threads": hw,
            "ms_per_iter_by_team": {str(k): 1e3 * v / ADMM_ITERS for k, v in sorted(tried.items())}}
     if kind == "reference":       # which binary this was: built by oracle/Makefile from /root/reference in the build container
@@ -139,24 +141,38 @@ def other_configs(pkg, torch, steps):
     mode (graph replay)."""
     res = {}
 
-    def measure(s, n_el, label):
+    def measure(s, n_el, label, warm=3):
         s.keep_z(False)
         s.initialize()
-        for _ in range(3):          # three warm-up frames (graph capture, cost-ordered launch, clocks), then the median of three timed runs
+        for _ in range(warm):       # warm-up frames (graph capture, cost-ordered launch, clocks) up to the STATED state ...
             s.step(ADMM_ITERS)
         s.sync()
-        runs = []
+        # ... which is kept (x, v, every force's u and warm start: the checkpoint of DESIGN 6d) and restored before each of the three timed
+        # runs: all three time the SAME frames warm+1 .. warm+steps of the simulation (the local step's cost moves with the deformation:
+        # consecutive windows of one simulation are not repeat measurements)
+        ck = dict(x=s.m_x.copy(), v=s.m_v.copy(), loc=[s.read_local(b) for b in range(len(s.batches))])
+
+        def rewind():
+            s.m_x = ck["x"]; s.m_v = ck["v"]
+            for bi, loc in enumerate(ck["loc"]):
+                s.write_local(bi, u=loc["u"], state=loc["state"] if pkg.KIND_STATE[s.batches[bi][0]] else None)
+            s.sync()
+        runs, sums = [], []
         for _ in range(3):
+            rewind()
             t = time.perf_counter()
             for _ in range(steps):
                 s.step(ADMM_ITERS)
             s.sync()
             runs.append((time.perf_counter() - t) / steps)
+            sums.append(float(np.abs(s.m_x).sum()))
         t = sorted(runs)[1]
         assert np.isfinite(s.m_x).all()
         inf = s.info()
         res[label] = {"value": ADMM_ITERS / t * n_el, "elements": int(n_el), "nodes": int(inf["n_nodes"]), "ms_per_iter": 1e3 * t / ADMM_ITERS,
                       "ms_per_iter_runs": [round(1e3 * r / ADMM_ITERS, 5) for r in runs],
+                      "frames_timed": "%d..%d of the simulation in every run (state rewound between runs)" % (warm + 1, warm + steps),
+                      "same_frames_every_run": bool(sums[0] == sums[1] == sums[2]),
                       "solve": "explicit inverse (one kernel)" if inf["dense_solve"] else "%d levels" % inf["n_levels"]}
     try:
         s = pkg.make_bar_system(10, 10, 9); measure(s, s.n_tets, "configs[1] NH bar 10x10x9 = 5400 tets"); del s
@@ -165,6 +181,18 @@ def other_configs(pkg, torch, steps):
     except Exception as e:  # noqa: BLE001 -- side figures; never lose the headline over them
         res["error"] = repr(e)
     return res
+
+
+def measured_roof(pm, sec):
+    """The launch's VALU instruction counts (PMC) priced at the issue rates MEASURED on this chip with saturated SIMDs
+    (tools/probe/valu_throughput.hip): the time below which no schedule of these instructions can finish."""
+    n = pm["SQ_INSTS_VALU"]["per_launch"]
+    tr = pm.get("SQ_INSTS_VALU_TRANS_F64", {}).get("per_launch")
+    if tr is None:
+        return {}
+    floor_s = ((n - tr) * VALU_NS_PER_INST_MEASURED + tr * VALU_NS_PER_TRANS_MEASURED) * 1e-9 / 1024.0
+    return {"trans_f64_insts": tr, "issue_floor_ms_measured_rates": 1e3 * floor_s, "valu_frac_measured_rates": floor_s / sec if sec > 0 else 0.0,
+            "measured_rates": "%.2f ns per wave-wide fp64 VALU instruction and SIMD, %.2f ns per v_rcp/v_rsq_f64 (saturated chip, profiles/r04/valu_roof.txt)" % (VALU_NS_PER_INST_MEASURED, VALU_NS_PER_TRANS_MEASURED)}
 
 
 def _cpu_model():
@@ -422,9 +450,16 @@ def main():
     valu = None
     sweeps = None
     bound = "hbm"
-    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r03/pmc_1M.json"))
+    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r04/pmc_1M.json"))
     if not os.path.exists(os.path.join(ROOT, pmc_file)):
-        pmc_file = os.path.join("profiles", "r02/pmc_1M.json")
+        pmc_file = os.path.join("profiles", "r03/pmc_1M.json")
+    pmc_stamp_ok = None      # True / False: the counter file carries the hash of the sources it was collected on (None: an unstamped, older file)
+    try:
+        stamp = json.load(open(os.path.join(ROOT, pmc_file))).get("csrc_sha256")
+        if stamp:
+            pmc_stamp_ok = bool(stamp == pkg._build.source_hash())
+    except Exception:  # noqa: BLE001
+        pass
     try:
         if (nx, ny, nz) == (32, 32, 163) and world == 1:
             kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
@@ -453,9 +488,12 @@ def main():
                         "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"]),
                         "issue_floor_ms": 1e3 * pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S,
                         "valu_frac": (pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S) / sec if sec > 0 else 0.0}
+                valu.update(measured_roof(pm, sec))
                 bound = "valu"
         if a.config == "mixed" and world == 1 and dom.startswith("project_multi_kernel"):      # the scene's one-launch local step: counters of tools/pmc_collect.sh with PMC_MIXED=1
-            pmc_file = os.path.join("profiles", "r03", "pmc_mixed.json")
+            pmc_file = os.path.join("profiles", "r04", "pmc_mixed.json")
+            if not os.path.exists(os.path.join(ROOT, pmc_file)):
+                pmc_file = os.path.join("profiles", "r03", "pmc_mixed.json")
             kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
             pm = kern[[k for k in kern if "project_multi_kernel" in k][0]]
             traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0
@@ -465,6 +503,7 @@ def main():
                     "lane_utilisation": pm["SQ_THREAD_CYCLES_VALU"]["per_launch"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]["per_launch"]),
                     "issue_floor_ms": 1e3 * pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S,
                     "valu_frac": (pm["SQ_INSTS_VALU"]["per_launch"] / VALU_ISSUE_SLOTS_PER_S) / sec if sec > 0 else 0.0}
+            valu.update(measured_roof(pm, sec))
             bound = "valu"
     except Exception as e:  # noqa: BLE001 -- counters are side information
         traffic = None
@@ -485,12 +524,15 @@ def main():
     roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
             "bytes_per_launch_min": (LOCAL_BYTES_PER_TET_MIN * (n_tets / world) if dom.startswith("project_tet_kernel") else by),
+            "frac_of_min_bytes": ((LOCAL_BYTES_PER_TET_MIN * (n_tets / world) if dom.startswith("project_tet_kernel") else by) / sec / 1e9 / HBM_PEAK_GBS) if sec > 0 else 0.0,
+            "valu_frac_measured_rates": (valu or {}).get("valu_frac_measured_rates"),
             "valu_frac": (valu or {}).get("valu_frac"),
             "note": ("bound = valu: the dominant kernel is limited by fp64 VALU issue / dependency latency; achieved / peak / frac keep the HBM yardstick "
                      "the contract asks for, valu_frac is the fraction of the roof that actually binds" if bound == "valu" else None),
             # achieved / avg_launch_ms are THIS run's HIP events; traffic / valu / sweeps.traffic are PMC counters and cannot be collected in
             # the same process: they come from the committed rocprofv3 --pmc passes of the same command (tools/pmc_collect.sh)
             "traffic_source": (pmc_file if (traffic is not None or sweeps is not None) else None),
+            "traffic_source_matches_this_tree": pmc_stamp_ok,
             "iteration": iteration, "sweeps": sweeps,
             "phases_ms_per_iter": {k: v / iters_total for k, v in phase.items()},
             "all": {k: {"GB/s": (v[0] / v[1] / 1e9 if v[1] > 0 else 0.0), "ms": v[1] * 1e3} for k, v in cands.items()}}

@@ -28,9 +28,15 @@ for d in sorted(glob.glob("/tmp/pmc_[0-9]*")):
 out = {}
 for k, cs in res.items():
     out[k] = {c: {"per_launch": sum(v[1].values()) / max(len(v[1]), 1), "launches": len(v[1])} for c, v in cs.items()}
+def _src_hash():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("b", os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "admm-elastic-sca_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.source_hash()
 mixed = len(sys.argv) > 2 and sys.argv[2]
 doc = {"workload": ("mixed scene of BASELINE configs[4] (26x26x123 bar, half NH half StVK tets, 158x158 cloth), 1 frame x 20 ADMM iterations, 1 MI355X" if mixed else "NH bar %s cubes, 1 frame x 20 ADMM iterations, 1 MI355X" % sys.argv[1]),
        "method": "rocprofv3 --kernel-trace --pmc <group>, one counter group per pass, command: python3 tools/run_steps.py <dims> 1 (tools/pmc_collect.sh); values are per launch (mean over launches, summed over a dispatch's instances). FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, both the raw and the x2 figure are quoted in DESIGN.md.",
+       "csrc_sha256": _src_hash(),      # the sources the counters were collected on (bench.py compares it with the tree it runs)
        "kernels": out}
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(doc, open("gpurun_out/pmc_mixed.json" if mixed else "gpurun_out/pmc_1M.json", "w"), indent=1)
