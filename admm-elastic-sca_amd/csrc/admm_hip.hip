@@ -158,6 +158,7 @@ struct admm_hip_ctx {
     // the class mirror and the bench do -- stops storing it in admm_hip_step; the parity entry points (local_step_only / local_step_dx)
     // and residual tracking always store it.  ADMM_HIP_KEEP_Z=0 / 1 overrides.
     bool keep_z = true, keep_z_user = true;
+    bool state_zero_copy = true;              // upload_state / download_state address the caller's page-locked vectors from ONE kernel each (any size; ADMM_HIP_STATE_ZEROCOPY=0: a DMA per vector + reordering kernels)
     int tet_lds_pad = 0;                      // ADMM_HIP_TET_LDS_PAD (probes only): unused dynamic LDS per tet block, caps the waves per SIMD (160 KB per CU)
     int tet_tpb = 0;                          // ADMM_HIP_TPB: tets per one-wave block (4 / 8 / 16 / 32 / 64) for the NH / StVK batches; 0 = 64
     bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
@@ -1465,7 +1466,8 @@ bool build_multi(admm_hip_ctx *ctx, admm_dev::MultiBatch &mb, int &blocks) {
         }
         if (code < 0 || !b.grp_ptr.empty() || mb.n == MULTI_MAX) return false;
         mb.b[mb.n] = batch_dev(ctx, b);
-        blocks += batch_blocks(b);
+        const int epl = (code == MK_BEND || code == MK_TRI_STRAIN || code == MK_TRI_AREA) ? MULTI_EPL : 1;      // these segments' blocks cover 64 * MULTI_EPL elements
+        blocks += (batch_blocks(b) + epl - 1) / epl;
         mb.code[mb.n] = code; mb.blk_end[mb.n] = blocks; ++mb.n;
     }
     if (mb.n < 2) return false;
@@ -2026,6 +2028,7 @@ int admm_hip_create(admm_hip_ctx **out, int device_id) {
     if (const char *g = getenv("ADMM_HIP_GROUPS")) { const int v = atoi(g); if (v >= 1 && v <= 8) ctx->groups = v; }
     if (const char *g = getenv("ADMM_HIP_PIPE")) { const int v = atoi(g); if (v >= 2 && v <= 8) { ctx->pipe = v; ctx->groups = v; } }
     if (const char *g = getenv("ADMM_HIP_PRERED")) ctx->tet_prered = atoi(g) != 0;
+    if (const char *g = getenv("ADMM_HIP_STATE_ZEROCOPY")) ctx->state_zero_copy = atoi(g) != 0;
     if (const char *g = getenv("ADMM_HIP_TET_LDS_PAD")) ctx->tet_lds_pad = std::max(0, atoi(g));
     if (const char *g = getenv("ADMM_HIP_TPB")) { const int v = atoi(g); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ctx->tet_tpb = v; }
     if (const char *g = getenv("ADMM_HIP_KEEP_Z")) ctx->keep_z_user = atoi(g) != 0;
@@ -2695,6 +2698,16 @@ int admm_hip_upload_state(admm_hip_ctx *ctx, const double *x, const double *v) {
         HIPCHK(hipEventRecord(ctx->state_in_ev, ctx->stream)); ctx->state_in_pending = true;
         return ADMM_OK;
     }
+    if (x && v && ctx->state_zero_copy && ctx->d_iperm) {      // the caller's page-locked vectors addressed by one kernel (no DMA, no staging)
+        void *dx = nullptr, *dv = nullptr;
+        if (hipHostGetDevicePointer(&dx, (void *)x, 0) == hipSuccess && hipHostGetDevicePointer(&dv, (void *)v, 0) == hipSuccess) {
+            hipLaunchKernelGGL(admm_dev::state_in2_kernel, dim3(std::min((2 * n3 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_iperm,
+                               (const double *)dx, (const double *)dv, ctx->d_x, ctx->d_v);
+            HIPCHK(hipGetLastError());
+            return ADMM_OK;
+        }
+        (void)hipGetLastError();      // not page-locked (admm_hip_pin_host was not called on them): the DMA path below
+    }
     if (x) {
         HIPCHK(hipMemcpyAsync(ctx->d_stage, x, bytes, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(admm_dev::permute_in_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_stage, ctx->d_x);
@@ -2718,6 +2731,17 @@ int admm_hip_download_state(admm_hip_ctx *ctx, double *x, double *v) {
         ctx->state_in_pending = false;
         std::memcpy(x, h, bytes); std::memcpy(v, h + n3, bytes);
         return ADMM_OK;
+    }
+    if (x && v && ctx->state_zero_copy && ctx->d_iperm) {
+        void *dx = nullptr, *dv = nullptr;
+        if (hipHostGetDevicePointer(&dx, (void *)x, 0) == hipSuccess && hipHostGetDevicePointer(&dv, (void *)v, 0) == hipSuccess) {
+            hipLaunchKernelGGL(admm_dev::state_out2_kernel, dim3(std::min((2 * n3 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_iperm,
+                               (const double *)ctx->d_x, (const double *)ctx->d_v, (double *)dx, (double *)dv);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            return ADMM_OK;
+        }
+        (void)hipGetLastError();
     }
     if (x) {
         hipLaunchKernelGGL(admm_dev::permute_out_kernel, dim3((n3 + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_nodes, (const int *)ctx->d_perm, (const double *)ctx->d_x, ctx->d_stage);

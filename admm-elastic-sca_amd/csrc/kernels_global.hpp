@@ -128,6 +128,24 @@ __global__ void state_in_kernel(int n_nodes, const int *__restrict__ iperm, cons
     const int j = i < n3 ? i : i - n3, node = j / 3, c = j - 3 * node;
     (i < n3 ? x_factor : v_factor)[3 * (size_t)iperm[node] + c] = host_xv[i];
 }
+// The same for systems of any size straight on the CALLER's page-locked vectors (admm_hip_pin_host; ADMM_HIP_STATE_ZEROCOPY): no staging
+// copy on either side, x and v in one launch, every lane one 8-byte word of the host vector (linear on the host side: coalesced PCIe bursts).
+__global__ __launch_bounds__(256) void state_in2_kernel(int n_nodes, const int *__restrict__ iperm, const double *__restrict__ host_x, const double *__restrict__ host_v,
+                                                        double *__restrict__ x_factor, double *__restrict__ v_factor) {
+    const int n3 = 3 * n_nodes;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n3; i += gridDim.x * blockDim.x) {
+        const int j = i < n3 ? i : i - n3, node = j / 3, c = j - 3 * node;
+        (i < n3 ? x_factor : v_factor)[3 * (size_t)iperm[node] + c] = __builtin_nontemporal_load(&(i < n3 ? host_x : host_v)[j]);
+    }
+}
+__global__ __launch_bounds__(256) void state_out2_kernel(int n_nodes, const int *__restrict__ iperm, const double *__restrict__ x_factor, const double *__restrict__ v_factor,
+                                                         double *__restrict__ host_x, double *__restrict__ host_v) {
+    const int n3 = 3 * n_nodes;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n3; i += gridDim.x * blockDim.x) {
+        const int j = i < n3 ? i : i - n3, node = j / 3, c = j - 3 * node;
+        __builtin_nontemporal_store((i < n3 ? x_factor : v_factor)[3 * (size_t)iperm[node] + c], &(i < n3 ? host_x : host_v)[j]);
+    }
+}
 __global__ void state_out_kernel(int n_nodes, const int *__restrict__ iperm, const double *__restrict__ x_factor, const double *__restrict__ v_factor, double *__restrict__ host_xv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, n3 = 3 * n_nodes;
     if (i >= 2 * n3) return;

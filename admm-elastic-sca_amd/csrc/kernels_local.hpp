@@ -468,65 +468,82 @@ __device__ __forceinline__ void project_spring_block(const BatchDev &b, const do
 // ---------------------------------------------------------------------------
 // BendForce, BendForce.cpp:131-161   rows (x0-x2, x3-x2, x1-x2)
 // ---------------------------------------------------------------------------
+// EPL elements per lane (block = 64 * EPL consecutive elements, a lane's elements 64 apart: every access stays coalesced): the kernel's
+// life is memory latency, so a lane that requests two elements' data at once halves the waves (and their round trips) of the launch.
+// Used by the one-launch local step, whose blocks run at the tet kinds' 2 waves per SIMD (project_multi_kernel); same arithmetic per element.
+template <int EPL = 1>
 __device__ __forceinline__ void project_bend_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
-    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
+    const int e0 = b.e0 + lb * (LOCAL_BLOCK * EPL) + threadIdx.x;
     const int n = b.n;
-    if (e >= b.e1) return;
+    if (e0 >= b.e1) return;
     // every load first, every store last: the stores to u / z may alias the loads as far as the compiler knows, and a load behind a store waits
     // for it (one in-order memory counter) -- per coordinate in turn the kernel was three dependent round trips long (31 us for 149 k hinges)
-    const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
-    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];
-    const double a0 = b.rest[(size_t)0 * n + e], a1 = b.rest[(size_t)1 * n + e], a3 = b.rest[(size_t)3 * n + e];
-    const double st = b.par[e], w2 = b.w2[e], s = b.w2h2[e];
-    double U[9];
+    int4 id[EPL], ds[EPL]; double a0[EPL], a1[EPL], a3[EPL], st[EPL], w2[EPL], s[EPL], U[EPL][9], X2[EPL][3], XP[EPL][3][3], DXO[EPL][9]; bool ok[EPL];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) U[q] = b.u[(size_t)q * n + e];
-    const int plus[3] = {id.x, id.w, id.y};
-    double X2[3], XP[3][3];
+    for (int t = 0; t < EPL; ++t) {
+        ok[t] = e0 + 64 * t < b.e1;
+        const int e = ok[t] ? e0 + 64 * t : e0;      // (a lane without a second element re-reads its first: no store)
+        id[t] = reinterpret_cast<const int4 *>(b.idx)[e];
+        ds[t] = reinterpret_cast<const int4 *>(b.dst)[e];
+        a0[t] = b.rest[(size_t)0 * n + e]; a1[t] = b.rest[(size_t)1 * n + e]; a3[t] = b.rest[(size_t)3 * n + e];
+        st[t] = b.par[e]; w2[t] = b.w2[e]; s[t] = b.w2h2[e];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        X2[j] = x[3 * (size_t)id.z + j];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) XP[r][j] = x[3 * (size_t)plus[r] + j];
+        for (int q = 0; q < 9; ++q) U[t][q] = b.u[(size_t)q * n + e];
     }
-    double DXO[9];
-    if (b.dx_override) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) DXO[q] = b.dx_override[(size_t)q * n + e];
-    }
-    const double den = a0 * a0 + a3 * a3 + a1 * a1;
-    const double cc = 1.0 / (w2 + st);
-    double UN[9], ZI[9], F[3][3];
+    for (int t = 0; t < EPL; ++t) {
+        const int plus[3] = {id[t].x, id[t].w, id[t].y};
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double x2 = X2[j];
-        double dx[3], u[3], d[3];
+        for (int j = 0; j < 3; ++j) {
+            X2[t][j] = x[3 * (size_t)id[t].z + j];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double xp = XP[r][j];
-            dx[r] = (plus[r] < id.z) ? ((0.0 + 1.0 * xp) + -1.0 * x2) : ((0.0 + -1.0 * x2) + 1.0 * xp);
-            if (b.dx_override) dx[r] = DXO[3 * r + j];
-            u[r] = U[3 * r + j];
-            d[r] = dx[r] + u[r];
+            for (int r = 0; r < 3; ++r) XP[t][r][j] = x[3 * (size_t)plus[r] + j];
         }
-        const double lam = 2.0 * (a0 * d[0] + a3 * d[1] + a1 * d[2]) / den;
-        const double p0 = d[0] - 0.5 * a0 * lam, p1 = d[1] - 0.5 * a3 * lam, p2 = d[2] - 0.5 * a1 * lam;
-        const double pr[3] = {p0, p1, p2};
+        if (b.dx_override) {
+            const int e = ok[t] ? e0 + 64 * t : e0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double zi = cc * (st * pr[r] + w2 * d[r]);
-            const double un = u[r] + (dx[r] - zi);
-            UN[3 * r + j] = un; ZI[3 * r + j] = zi;
-            F[r][j] = s * (zi - un);
+            for (int q = 0; q < 9; ++q) DXO[t][q] = b.dx_override[(size_t)q * n + e];
         }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) { b.u[(size_t)q * n + e] = UN[q]; b.z[(size_t)q * n + e] = ZI[q]; }
-    // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
-    double *o0 = b.fslot + 3 * (size_t)ds.x, *o1 = b.fslot + 3 * (size_t)ds.y, *o2 = b.fslot + 3 * (size_t)ds.z, *o3 = b.fslot + 3 * (size_t)ds.w;
+    for (int t = 0; t < EPL; ++t) {
+        if (!ok[t]) continue;
+        const int e = e0 + 64 * t;
+        const int plus[3] = {id[t].x, id[t].w, id[t].y};
+        const double den = a0[t] * a0[t] + a3[t] * a3[t] + a1[t] * a1[t];
+        const double cc = 1.0 / (w2[t] + st[t]);
+        double UN[9], ZI[9], F[3][3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        o0[j] = F[0][j]; o1[j] = F[2][j]; o2[j] = -((F[0][j] + F[1][j]) + F[2][j]); o3[j] = F[1][j];
+        for (int j = 0; j < 3; ++j) {
+            const double x2 = X2[t][j];
+            double dx[3], u[3], d[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double xp = XP[t][r][j];
+                dx[r] = (plus[r] < id[t].z) ? ((0.0 + 1.0 * xp) + -1.0 * x2) : ((0.0 + -1.0 * x2) + 1.0 * xp);
+                if (b.dx_override) dx[r] = DXO[t][3 * r + j];
+                u[r] = U[t][3 * r + j];
+                d[r] = dx[r] + u[r];
+            }
+            const double lam = 2.0 * (a0[t] * d[0] + a3[t] * d[1] + a1[t] * d[2]) / den;
+            const double p0 = d[0] - 0.5 * a0[t] * lam, p1 = d[1] - 0.5 * a3[t] * lam, p2 = d[2] - 0.5 * a1[t] * lam;
+            const double pr[3] = {p0, p1, p2};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double zi = cc * (st[t] * pr[r] + w2[t] * d[r]);
+                const double un = u[r] + (dx[r] - zi);
+                UN[3 * r + j] = un; ZI[3 * r + j] = zi;
+                F[r][j] = s[t] * (zi - un);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { b.u[(size_t)q * n + e] = UN[q]; b.z[(size_t)q * n + e] = ZI[q]; }
+        // corners in idx order: 0 -> row block 0, 1 -> row block 2, 2 -> minus all, 3 -> row block 1
+        double *o0 = b.fslot + 3 * (size_t)ds[t].x, *o1 = b.fslot + 3 * (size_t)ds[t].y, *o2 = b.fslot + 3 * (size_t)ds[t].z, *o3 = b.fslot + 3 * (size_t)ds[t].w;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            o0[j] = F[0][j]; o1[j] = F[2][j]; o2[j] = -((F[0][j] + F[1][j]) + F[2][j]); o3[j] = F[1][j];
+        }
     }
 }
 
@@ -535,81 +552,102 @@ __device__ __forceinline__ void project_bend_block(const BatchDev &b, const doub
 // strain-limited; MODE 1: TriArea (:251-295); MODE 2: FungTriangle (:227-249).  All three run the bit-exact restatement of
 // Eigen's JacobiSVD<3x2> (column-pivoted Householder QR + 2x2 Jacobi, local_math.hpp svd32): bit-identical with the reference.
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int EPL = 1>
 __device__ __forceinline__ void project_tri_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
-    const int e = b.e0 + lb * LOCAL_BLOCK + threadIdx.x;
+    const int e0 = b.e0 + lb * (LOCAL_BLOCK * EPL) + threadIdx.x;
     const int n = b.n;
-    if (e >= b.e1) return;
-    const int4 id = reinterpret_cast<const int4 *>(b.idx)[e];
-    const int4 ds = reinterpret_cast<const int4 *>(b.dst)[e];      // (with the other loads: behind the u / z stores it would wait for them)
-    const int i0 = id.x, i1 = id.y, i2 = id.z;
-    // (parameters with the first burst of loads, not after the SVD: one exposed round trip less in a wave whose life is memory latency)
-    const double kb = MODE != 2 ? b.kblend[e] : 0.0, w2e = MODE != 2 ? b.w2[e] : 0.0;
-    const double par1 = MODE != 2 ? b.par[(size_t)1 * n + e] : 0.0, par2 = MODE != 2 ? b.par[(size_t)2 * n + e] : 0.0, par3 = MODE != 2 ? b.par[(size_t)3 * n + e] : 0.0;
-    double B[6];
+    if (e0 >= b.e1) return;
+    // all loads of the lane's EPL elements first (see project_bend_block), then element after element: arithmetic, stores
+    int4 id[EPL], ds[EPL]; bool ok[EPL];
+    double kb[EPL], w2e[EPL], par1[EPL], par2[EPL], par3[EPL], s[EPL], B[EPL][6], XA[EPL][3], XB[EPL][3], XC[EPL][3], U[EPL][6], DXO[EPL][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) B[i] = b.rest[(size_t)i * n + e];
-    double dx[6], u[6], d[6];
+    for (int t = 0; t < EPL; ++t) {
+        ok[t] = e0 + 64 * t < b.e1;
+        const int e = ok[t] ? e0 + 64 * t : e0;
+        id[t] = reinterpret_cast<const int4 *>(b.idx)[e];
+        ds[t] = reinterpret_cast<const int4 *>(b.dst)[e];      // (with the other loads: behind the u / z stores it would wait for them)
+        // (parameters with the first burst of loads, not after the SVD: one exposed round trip less in a wave whose life is memory latency)
+        kb[t] = MODE != 2 ? b.kblend[e] : 0.0; w2e[t] = MODE != 2 ? b.w2[e] : 0.0;
+        par1[t] = MODE != 2 ? b.par[(size_t)1 * n + e] : 0.0; par2[t] = MODE != 2 ? b.par[(size_t)2 * n + e] : 0.0; par3[t] = MODE != 2 ? b.par[(size_t)3 * n + e] : 0.0;
+        s[t] = b.w2h2[e];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double xa = x[3 * (size_t)i0 + j], xb = x[3 * (size_t)i1 + j], xc = x[3 * (size_t)i2 + j];
+        for (int i = 0; i < 6; ++i) { B[t][i] = b.rest[(size_t)i * n + e]; U[t][i] = b.u[(size_t)i * n + e]; }
+    }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            dx[3 * r + j] = ((0.0 + B[0 + 3 * r] * xa) + B[1 + 3 * r] * xb) + B[2 + 3 * r] * xc;
-            if (b.dx_override) dx[3 * r + j] = b.dx_override[(size_t)(3 * r + j) * n + e];
-            u[3 * r + j] = b.u[(size_t)(3 * r + j) * n + e];
-            d[3 * r + j] = dx[3 * r + j] + u[3 * r + j];
+    for (int t = 0; t < EPL; ++t) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { XA[t][j] = x[3 * (size_t)id[t].x + j]; XB[t][j] = x[3 * (size_t)id[t].y + j]; XC[t][j] = x[3 * (size_t)id[t].z + j]; }
+        if (b.dx_override) {
+            const int e = ok[t] ? e0 + 64 * t : e0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) DXO[t][i] = b.dx_override[(size_t)i * n + e];
         }
     }
-    double zi[6];
-    const double s = b.w2h2[e];
-    if (MODE == 0) {
-        // T = U(:, :2) V^T from the reference's own 3x2 Jacobi SVD (TriangleForce.cpp:83-92): bit-identical with it.
-        // (The closed form F (F^T F)^-1/2 is 4x cheaper and agrees to 1e-12, but this kernel is bandwidth-bound anyway.)
-        double U2[6], V[4], sv0, sv1, T[6];
-        svd32(d, U2, sv0, sv1, V);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int t = 0; t < EPL; ++t) {
+        if (!ok[t]) continue;
+        const int e = e0 + 64 * t;
+        double dx[6], u[6], d[6];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) T[i + 3 * j] = U2[i] * V[j] + U2[i + 3] * V[j + 2];
-        const double k = kb, w2 = w2e;
+        for (int j = 0; j < 3; ++j) {
+            const double xa = XA[t][j], xb = XB[t][j], xc = XC[t][j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
-        if (par3 != 0.0) {
-            const double lmin = par1, lmax = par2;
-            const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
-            const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
-            const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
-            if (l0 < lmin) { const double sc = lmin / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
-            if (l1 < lmin) { const double sc = lmin / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
-            if (l0 > lmax) { const double sc = lmax / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
-            if (l1 > lmax) { const double sc = lmax / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+            for (int r = 0; r < 2; ++r) {
+                dx[3 * r + j] = ((0.0 + B[t][0 + 3 * r] * xa) + B[t][1 + 3 * r] * xb) + B[t][2 + 3 * r] * xc;
+                if (b.dx_override) dx[3 * r + j] = DXO[t][3 * r + j];
+                u[3 * r + j] = U[t][3 * r + j];
+                d[3 * r + j] = dx[3 * r + j] + u[3 * r + j];
+            }
         }
-    } else if (MODE == 1) {
-        double p[6];
-        project_triarea_p(d, (int)par1, par2, par3, p);
-        const double k = kb, w2 = w2e;
+        double zi[6];
+        if (MODE == 0) {
+            // T = U(:, :2) V^T from the reference's own 3x2 Jacobi SVD (TriangleForce.cpp:83-92): bit-identical with it.
+            // (The closed form F (F^T F)^-1/2 is 4x cheaper and agrees to 1e-12, but this kernel is bandwidth-bound anyway.)
+            double U2[6], V[4], sv0, sv1, T[6];
+            svd32(d, U2, sv0, sv1, V);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zi[i] = (k * p[i] + w2 * d[i]) / (w2 + k);
-    } else {
-        double hs = b.state[(size_t)3 * n + e];
-        int it = 0;
-        project_fung(d, b.par[e], hs, it, zi);
-        b.state[(size_t)3 * n + e] = hs;
-        b.n_iters[e] = it;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) T[i + 3 * j] = U2[i] * V[j] + U2[i + 3] * V[j + 2];
+            const double k = kb[t], w2 = w2e[t];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) zi[i] = (k * T[i] + w2 * d[i]) / (w2 + k);
+            if (par3[t] != 0.0) {
+                const double lmin = par1[t], lmax = par2[t];
+                const double l0 = sqrt(zi[0] * zi[0] + (zi[1] * zi[1] + zi[2] * zi[2]));
+                const double l1 = sqrt(zi[3] * zi[3] + (zi[4] * zi[4] + zi[5] * zi[5]));
+                const double m0 = (double)fmaxf((float)l0, (float)1e-6), m1 = (double)fmaxf((float)l1, (float)1e-6);
+                if (l0 < lmin) { const double sc = lmin / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+                if (l1 < lmin) { const double sc = lmin / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+                if (l0 > lmax) { const double sc = lmax / m0; zi[0] *= sc; zi[1] *= sc; zi[2] *= sc; }
+                if (l1 > lmax) { const double sc = lmax / m1; zi[3] *= sc; zi[4] *= sc; zi[5] *= sc; }
+            }
+        } else if (MODE == 1) {
+            double p[6];
+            project_triarea_p(d, (int)par1[t], par2[t], par3[t], p);
+            const double k = kb[t], w2 = w2e[t];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) zi[i] = (k * p[i] + w2 * d[i]) / (w2 + k);
+        } else {
+            double hs = b.state[(size_t)3 * n + e];
+            int it = 0;
+            project_fung(d, b.par[e], hs, it, zi);
+            b.state[(size_t)3 * n + e] = hs;
+            b.n_iters[e] = it;
+        }
+        double q[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double un = u[i] + (dx[i] - zi[i]);
+            b.u[(size_t)i * n + e] = un; b.z[(size_t)i * n + e] = zi[i];
+            q[i] = zi[i] - un;
+        }
+        const int dsl[3] = {ds[t].x, ds[t].y, ds[t].z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)dsl[c] + j] = s[t] * (B[t][c] * q[j] + B[t][c + 3] * q[3 + j]);
     }
-    double q[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double un = u[i] + (dx[i] - zi[i]);
-        b.u[(size_t)i * n + e] = un; b.z[(size_t)i * n + e] = zi[i];
-        q[i] = zi[i] - un;
-    }
-    const int dsl[3] = {ds.x, ds.y, ds.z};
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) b.fslot[3 * (size_t)dsl[c] + j] = s * (B[c] * q[j] + B[c + 3] * q[3 + j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -617,9 +655,9 @@ __device__ __forceinline__ void project_tri_block(const BatchDev &b, const doubl
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_collision_kernel(BatchDev b, const double *__restrict__ x, const ShapeTable *__restrict__ shapes) { project_collision_block(b, x, shapes, (int)blockIdx.x); }
 __global__ __launch_bounds__(LOCAL_BLOCK) void project_spring_kernel(BatchDev b, const double *__restrict__ x) { project_spring_block(b, x, (int)blockIdx.x); }
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) { project_bend_block(b, x, (int)blockIdx.x); }
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_bend_kernel(BatchDev b, const double *__restrict__ x) { project_bend_block<1>(b, x, (int)blockIdx.x); }
 template <int MODE>
-__global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) { project_tri_block<MODE>(b, x, (int)blockIdx.x); }
+__global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, const double *__restrict__ x) { project_tri_block<MODE, 1>(b, x, (int)blockIdx.x); }
 
 // ... or the WHOLE local step of a scene with several batches in ONE launch (System.cpp:57-58 is one loop over all forces): the
 // batches' blocks back to back in list order.  Launched one after the other, every batch ends with a tail of a few slow waves on a
@@ -627,6 +665,10 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 // the next batch's blocks fill the slots the tail leaves.  Side streams do the same but pay 10-25 us per cross-stream dependency.
 // Same per-element arithmetic, own outputs per element: bitwise the same results.
 constexpr int MULTI_MAX = 8;
+#ifndef ADMM_MULTI_EPL
+#define ADMM_MULTI_EPL 2
+#endif
+constexpr int MULTI_EPL = ADMM_MULTI_EPL;      // hinges and strain / area triangles inside the one-launch local step: elements per lane (see project_bend_block)
 enum { MK_TET_NH = 0, MK_TET_STVK, MK_TET_LINEAR, MK_TET_VOLUME, MK_ANCHOR, MK_SPRING, MK_BEND, MK_TRI_STRAIN, MK_TRI_AREA, MK_TRI_FUNG, MK_COLLISION };
 // (Tried: the segments' blocks interleaved in proportion through a workgroup -> (segment, block) table, so that the memory-bound blocks of the cheap kinds
 // share the SIMDs with the tet blocks all along the launch: local step of the mixed scene 0.178 -> 0.196 ms -- dearest first, back to back, is the better schedule.)
@@ -649,10 +691,10 @@ void project_multi_kernel(MultiBatch a, const double *__restrict__ x, const Shap
     case MK_TET_VOLUME: project_tet_block<3, 1, false>(b, x, lb, stage); break;
     case MK_ANCHOR: project_anchor_elem<false>(b, x, b.e0 + lb * LOCAL_BLOCK + threadIdx.x, lb); break;
     case MK_SPRING: project_spring_block(b, x, lb); break;
-    case MK_BEND: project_bend_block(b, x, lb); break;
-    case MK_TRI_STRAIN: project_tri_block<0>(b, x, lb); break;
-    case MK_TRI_AREA: project_tri_block<1>(b, x, lb); break;
-    case MK_TRI_FUNG: project_tri_block<2>(b, x, lb); break;
+    case MK_BEND: project_bend_block<MULTI_EPL>(b, x, lb); break;
+    case MK_TRI_STRAIN: project_tri_block<0, MULTI_EPL>(b, x, lb); break;
+    case MK_TRI_AREA: project_tri_block<1, MULTI_EPL>(b, x, lb); break;
+    case MK_TRI_FUNG: project_tri_block<2, 1>(b, x, lb); break;
     case MK_COLLISION: project_collision_block(b, x, shapes, lb); break;
     default: break;
     }

@@ -575,26 +575,48 @@ def main():
         hx = s.m_x.copy(); hv = s.m_v.copy()
         s.pin_host(hx); s.pin_host(hv)
         s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
-        nf = max(a.steps, 12)        # 12+ frames each, alternated in blocks of 4 so that clock drift hits both alike
+        # The cost of a frame moves with the simulation (the line searches lengthen as the bar deforms), so both loops run the SAME frames:
+        # checkpoint (x, v, every force's u and warm start), nf frames resident, rewind, the same nf frames through the class API -- twice.
+        nf = max(a.steps, 8)
+        ck = dict(x=s.m_x.copy(), v=s.m_v.copy(), loc=[s.read_local(b) for b in range(len(s.batches))])
+
+        def rewind():
+            s.m_x = ck["x"]; s.m_v = ck["v"]
+            for bi, loc in enumerate(ck["loc"]):
+                s.write_local(bi, u=loc["u"], state=loc["state"] if pkg.KIND_STATE[s.batches[bi][0]] else None)
+            s.sync()
         tc = tr = 0.0
-        for _ in range(nf // 4):
+        sums = []
+        for _ in range(2):
+            rewind()
             t = time.perf_counter()
-            for _ in range(4):
-                s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
-            tc += time.perf_counter() - t
-            t = time.perf_counter()
-            for _ in range(4):
+            for _ in range(nf):
                 s.step(ADMM_ITERS)
             s.sync()
             tr += time.perf_counter() - t
-        nf = 4 * (nf // 4)
+            sums.append(float(np.abs(s.m_x).sum()))
+            rewind()
+            hx[:] = ck["x"]; hv[:] = ck["v"]
+            t = time.perf_counter()
+            for _ in range(nf):
+                s.upload_state(hx, hv); s.step(ADMM_ITERS); s.download_state(hx, hv)
+            tc += time.perf_counter() - t
+            sums.append(float(np.abs(hx).sum()))
+        same = bool(len(set(sums)) == 1)
+        nf *= 2
         tc /= nf; tr /= nf
+        t = time.perf_counter()          # the four transfers (+ the reordering kernels) on their own: what the boundary costs when nothing hides it
+        for _ in range(8):
+            s.upload_state(hx, hv); s.download_state(hx, hv)
+        tx = (time.perf_counter() - t) / 8
         s.pin_host(hx, False); s.pin_host(hv, False)
         pcie_floor = 4.0 * 8.0 * 3 * info["n_nodes"] / 64e9         # four vectors over PCIe 5 x16 (64 GB/s each way)
         out["class_api"] = {"ms_per_step": 1e3 * tc, "resident_ms_per_step": 1e3 * tr, "value": ADMM_ITERS / tc * n_tets, "overhead_frac": tc / tr - 1.0,
                             "pcie_floor_frac": pcie_floor / tr, "frames": nf,
+                            "transfers_alone_ms": 1e3 * tx, "transfers_alone_frac": tx / tr, "transfers_GBps": 4.0 * 8.0 * 3 * info["n_nodes"] / tx / 1e9,
                             "what": "admm_hip_upload_state(m_x, m_v) + admm_hip_step + admm_hip_download_state(m_x, m_v) per frame, event-free, "
-                                    "vs. the same %d frames with the state resident (blocks of 4 frames alternated)" % nf}
+                                    "vs. the SAME %d frames (state rewound to one checkpoint before every block) with the state resident" % nf,
+                            "same_frames_both_ways": same}
         out["other_configs"] = other_configs(pkg, torch, a.steps)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 side figure

@@ -12,11 +12,16 @@ pkg = load_package()
 sims = {}
 for name in ("class API",):
     dims = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 32, 163)
+    trace = len(sys.argv) > 4 and sys.argv[4] == "trace"      # under rocprofv3 (tools/class_api_timeline.py): three class-API frames, nothing else
     s = pkg.make_bar_system(*dims); s.keep_z(False); s.initialize()
     s.step(20); s.sync()
     hx = s.m_x.copy(); hv = s.m_v.copy(); s.pin_host(hx); s.pin_host(hv)
     sims[name] = (s, hx, hv)
-N = 6 if len(sys.argv) < 4 else 40
+N = 6 if len(sys.argv) < 4 or (len(sys.argv) > 4 and sys.argv[4] == "trace") else 40
+if len(sys.argv) > 4 and sys.argv[4] == "trace":
+    s, hx, hv = sims["class API"]
+    for _ in range(3): s.upload_state(hx, hv); s.step(20); s.download_state(hx, hv)
+    sys.exit(0)
 for r in range(3):
     for name, (s, hx, hv) in sims.items():
         t = time.perf_counter()
