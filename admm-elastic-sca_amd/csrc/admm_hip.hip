@@ -2272,8 +2272,8 @@ extern "C" int admm_hip_debug_tet_trace_read(float *out) {
 }
 // tools/tet_phase_profile.py only (variant build): read and clear the tet kernel's phase counters
 extern "C" int admm_hip_debug_tet_profile(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 96) != hipSuccess) return ADMM_ERR_HIP;
-    unsigned long long zero[96] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(admm_dev::g_tet_prof), sizeof(unsigned long long) * 128) != hipSuccess) return ADMM_ERR_HIP;
+    unsigned long long zero[128] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(admm_dev::g_tet_prof), zero, sizeof(zero)) != hipSuccess) return ADMM_ERR_HIP;
     return ADMM_OK;
 }

@@ -240,6 +240,7 @@ __device__ __forceinline__ void project_tet_block(const BatchDev &b, const doubl
     Mat3 Dx, u, F, z;
     Mat3 zp;      // TRACK: z of the previous iteration
     ADMM_PROF_T0
+    ADMM_PROF_REGION(0);      // a wave of the tet kernel
     ADMM_TET_STAMP(lb, 0, __builtin_amdgcn_s_memrealtime());
     tet_load(b, x, e, n, B, Dx, u);
     F = mat_add(Dx, u);
@@ -468,9 +469,8 @@ __device__ __forceinline__ void project_spring_block(const BatchDev &b, const do
 // ---------------------------------------------------------------------------
 // BendForce, BendForce.cpp:131-161   rows (x0-x2, x3-x2, x1-x2)
 // ---------------------------------------------------------------------------
-// EPL elements per lane (block = 64 * EPL consecutive elements, a lane's elements 64 apart: every access stays coalesced): the kernel's
-// life is memory latency, so a lane that requests two elements' data at once halves the waves (and their round trips) of the launch.
-// Used by the one-launch local step, whose blocks run at the tet kinds' 2 waves per SIMD (project_multi_kernel); same arithmetic per element.
+// EPL elements per lane (block = 64 * EPL consecutive elements, a lane's elements 64 apart: every access stays coalesced); same arithmetic
+// per element.  EPL = 2 was meant for the one-launch local step (MULTI_EPL below: measured, no effect); every launch uses 1.
 template <int EPL = 1>
 __device__ __forceinline__ void project_bend_block(const BatchDev &b, const double *__restrict__ x, const int lb) {
     const int e0 = b.e0 + lb * (LOCAL_BLOCK * EPL) + threadIdx.x;
@@ -666,9 +666,12 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 // Same per-element arithmetic, own outputs per element: bitwise the same results.
 constexpr int MULTI_MAX = 8;
 #ifndef ADMM_MULTI_EPL
-#define ADMM_MULTI_EPL 2
+#define ADMM_MULTI_EPL 1
 #endif
-constexpr int MULTI_EPL = ADMM_MULTI_EPL;      // hinges and strain / area triangles inside the one-launch local step: elements per lane (see project_bend_block)
+// hinges and strain / area triangles inside the one-launch local step: elements per lane (see project_bend_block).  Two per lane were built to
+// give these latency-bound segments twice the loads in flight at the tet kinds' 2 waves per SIMD -- A/B'd as two builds, three alternations on one
+// box (profiles/r04/mixed_epl_ab.txt): local step of the mixed scene 157.8 / 156.4 / 157.6 us against 157.2 / 157.1 / 156.1 with one: no effect, so one.
+constexpr int MULTI_EPL = ADMM_MULTI_EPL;
 enum { MK_TET_NH = 0, MK_TET_STVK, MK_TET_LINEAR, MK_TET_VOLUME, MK_ANCHOR, MK_SPRING, MK_BEND, MK_TRI_STRAIN, MK_TRI_AREA, MK_TRI_FUNG, MK_COLLISION };
 // (Tried: the segments' blocks interleaved in proportion through a workgroup -> (segment, block) table, so that the memory-bound blocks of the cheap kinds
 // share the SIMDs with the tet blocks all along the launch: local step of the mixed scene 0.178 -> 0.196 ms -- dearest first, back to back, is the better schedule.)

@@ -54,7 +54,8 @@ __device__ __forceinline__ unsigned long long wave_max_u(int v) {
 // ---- phase attribution of the tet kernel (tools/tet_phase_profile.py; build flag -DADMM_TET_PROFILE, never on in the
 // shipped library): s_memtime deltas accumulated by lane 0 of every wave, per-lane loop counts as (sum, 64 x wave maximum)
 #if defined(ADMM_TET_PROFILE) && defined(__HIPCC__)
-__device__ unsigned long long g_tet_prof[96];   // [0..31] phase ticks / loop counts, [32..63] histogram of line-search evaluations per tet, [64..95] of the wave maxima
+__device__ unsigned long long g_tet_prof[128];  // [0..31] phase ticks / loop counts, [32..63] histogram of line-search evaluations per tet, [64..95] of the wave maxima,
+                                                // [96..127] how many times a WAVE executed each code region (ADMM_PROF_REGION; tools/audit/tet_inst_by_region.py)
 __device__ float *g_tet_trace;                  // per tet of the current launch: [max |gradient| at the warm start, line-search evaluations] (tools/probe/ls_predict_gpu.py)
 #endif
 #if defined(ADMM_TET_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -79,12 +80,15 @@ __device__ __forceinline__ void prof_hist(int v) {
 }
 #define ADMM_PROF_COUNT(i, v) admm_dev::prof_count(i, v)
 #define ADMM_PROF_HIST(v) admm_dev::prof_hist(v)
+// one count per WAVE that reaches this point with any lane active (a wave issues a region's instructions once, whatever its lane count)
+#define ADMM_PROF_REGION(i) do { const unsigned long long a_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)a_) - 1) atomicAdd(&admm_dev::g_tet_prof[96 + (i)], 1ull); } while (0)
 #define ADMM_PROF_ON 1
 #else
 #define ADMM_PROF_T0
 #define ADMM_PROF_TIME(i)
 #define ADMM_PROF_COUNT(i, v)
 #define ADMM_PROF_HIST(v)
+#define ADMM_PROF_REGION(i)
 #define ADMM_PROF_ON 0
 #endif
 
@@ -208,6 +212,7 @@ template <int P, int Q> ADMM_HD bool jacobi_pq(Mat3 &W, Mat3 &U, Mat3 &V) {
     double wpp = at<P, P>(W), wqq = at<Q, Q>(W), wpq = at<P, Q>(W), wqp = at<Q, P>(W);
     double threshold = smax(considerAsZero, precision * smax(fabs(wpp), fabs(wqq)));
     if (!(fabs(wpq) > threshold || fabs(wqp) > threshold)) return false;
+    ADMM_PROF_REGION(2);      // a Jacobi rotation (any pair)
     double m00 = wpp, m01 = wpq, m10 = wqp, m11 = wqq;
     double c1, s1;
     double t = m00 + m11, d = m10 - m01;
@@ -265,6 +270,7 @@ ADMM_HD void svd3(const Mat3 &F, Mat3 &U, double &s0, double &s1, double &s2, Ma
     int prof_sweeps = 0, prof_rot = 0;
 #endif
     while (!finished) {
+        ADMM_PROF_REGION(1);      // a Jacobi sweep
         bool a = jacobi_pq<1, 0>(W, U, V);
         bool b = jacobi_pq<2, 0>(W, U, V);
         bool c = jacobi_pq<2, 1>(W, U, V);
@@ -335,11 +341,32 @@ static const double g_log_tab[256] = ADMM_LOG_TAB;
 #endif
 ADMM_HD unsigned long long dbl_bits(double x) { unsigned long long u; __builtin_memcpy(&u, &x, 8); return u; }
 ADMM_HD double bits_dbl(unsigned long long u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+// the table path on the bits of a positive, finite, NORMAL argument.  32-bit words on purpose: every constant involved has a zero low word,
+// so the 64-bit subtractions, the shift by 52 and the int64 -> double conversion of glibc's source are one-word operations here (hipcc
+// kept them two-word: 12 more instructions per call, and the kernels sit on the VALU issue roof)
+ADMM_HD double admm_log_table(unsigned hi, unsigned lo) {
+    const double A[5] = ADMM_LOG_A;
+    const unsigned tmp_hi = hi - 0x3fe60000u;                        // tmp = ix - 0x3fe6000000000000
+    const int i = (int)((tmp_hi >> 13) & 127u);                      // (tmp >> 45) & 127
+    const int k = (int)tmp_hi >> 20;                                 // (int64) tmp >> 52
+    const double z = bits_dbl(((unsigned long long)(hi - (tmp_hi & 0xfff00000u)) << 32) | lo);      // ix - (tmp & 0xfff0000000000000)
+    const double invc = g_log_tab[2 * i], logc = g_log_tab[2 * i + 1];
+    const double kd = (double)k;
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double w = __builtin_fma(kd, ADMM_LOG_LN2HI, logc);
+    const double hi_ = w + r;
+    const double lo_ = __builtin_fma(kd, ADMM_LOG_LN2LO, (w - hi_) + r);
+    const double r2 = r * r;
+    const double q = __builtin_fma(__builtin_fma(r, A[4], A[3]), r2, __builtin_fma(r, A[2], A[1]));
+    return __builtin_fma(r * r2, q, __builtin_fma(r2, A[0], lo_)) + hi_;
+}
 ADMM_HD double admm_log(double x) {
-    const double A[5] = ADMM_LOG_A, B[11] = ADMM_LOG_B;
-    unsigned long long ix = dbl_bits(x);
+    const double B[11] = ADMM_LOG_B;
+    const unsigned long long ix = dbl_bits(x);
+    const unsigned hi = (unsigned)(ix >> 32), lo = (unsigned)ix;
     double res;
-    if (ix - 0x3fee000000000000ull < 0x0003090000000000ull) {       // 1 - 0x1p-4 <= x < 1 + 0x1.09p-4
+    if (hi - 0x3fee0000u < 0x00030900u) {                            // 1 - 0x1p-4 <= x < 1 + 0x1.09p-4  (ix - 0x3fee000000000000 < 0x0003090000000000)
+        ADMM_PROF_REGION(11);
         const double r = x - 1.0;
         const double r2 = r * r, r3 = r * r2;
         const double p1 = __builtin_fma(r2, B[3], __builtin_fma(r, B[2], B[1]));
@@ -351,33 +378,23 @@ ADMM_HD double admm_log(double x) {
         const double rhi = __builtin_fma(-0x1p27, r, t);            // (r + w) - w
         const double rlo = r - rhi;
         const double rh2 = rhi * rhi;
-        const double hi = __builtin_fma(rh2, B[0], r);
-        double lo = __builtin_fma(rh2, B[0], r - hi);
-        lo = __builtin_fma(B[0] * rlo, r + rhi, lo);
-        res = hi + __builtin_fma(pol, r3, lo);
+        const double h = __builtin_fma(rh2, B[0], r);
+        double l = __builtin_fma(rh2, B[0], r - h);
+        l = __builtin_fma(B[0] * rlo, r + rhi, l);
+        res = h + __builtin_fma(pol, r3, l);
         if (ix == 0x3ff0000000000000ull) res = 0.0;
     } else {
-        const unsigned top = (unsigned)(ix >> 48);
-        const bool special = top - 0x0010u >= 0x7ff0u - 0x0010u;      // zero, subnormal, negative, inf, nan
-        if (special) ix = dbl_bits(x * 0x1p52) - (52ull << 52);       // (subnormal: renormalise; the others are overridden below)
-        const unsigned long long tmp = ix - 0x3fe6000000000000ull;
-        const int i = (int)((tmp >> 45) & 127);
-        const int k = (int)((long long)tmp >> 52);
-        const double z = bits_dbl(ix - (tmp & 0xfff0000000000000ull));
-        const double invc = g_log_tab[2 * i], logc = g_log_tab[2 * i + 1];
-        const double kd = (double)k;
-        const double r = __builtin_fma(z, invc, -1.0);
-        const double w = __builtin_fma(kd, ADMM_LOG_LN2HI, logc);
-        const double hi = w + r;
-        const double lo = __builtin_fma(kd, ADMM_LOG_LN2LO, (w - hi) + r);
-        const double r2 = r * r;
-        const double q = __builtin_fma(__builtin_fma(r, A[4], A[3]), r2, __builtin_fma(r, A[2], A[1]));
-        res = __builtin_fma(r * r2, q, __builtin_fma(r2, A[0], lo)) + hi;
-        if (special) {
-            const unsigned long long ax = dbl_bits(x);
-            if (ax * 2 == 0) res = -__builtin_inf();
-            else if (ax == 0x7ff0000000000000ull) res = x;
+        ADMM_PROF_REGION(10);
+        res = admm_log_table(hi, lo);
+        const unsigned top = hi >> 16;
+        if (top - 0x0010u >= 0x7ff0u - 0x0010u) {                    // zero, subnormal, negative, inf, nan: rare, and behind a branch a wave without such a lane skips
+            if (ix * 2 == 0) res = -__builtin_inf();
+            else if (ix == 0x7ff0000000000000ull) res = x;
             else if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) res = __builtin_nan("");
+            else {                                                   // subnormal: renormalise, then the same path
+                const unsigned long long is = dbl_bits(x * 0x1p52) - (52ull << 52);
+                res = admm_log_table((unsigned)(is >> 32), (unsigned)is);
+            }
         }
     }
     return res;
@@ -600,6 +617,7 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         stp = smin(stp, stpmax);
         if ((brackt && ((stp <= stmin) | (stp >= stmax))) | (nfev >= maxfev - 1) | (infoc == 0) | (brackt & (stmax - stmin <= xtol * stmax))) stp = stx;
         V3 xn; xn.a = x.a + stp * s.a; xn.b = x.b + stp * s.b; xn.c = x.c + stp * s.c;
+        ADMM_PROF_REGION(8);      // a line-search evaluation
 #if ADMM_PROF_ON && defined(__HIP_DEVICE_COMPILE__)
         {   // how many evaluations happen at a point that was evaluated just before (the previous trial point or the base point)?
             const bool rep = (xn.a == prof_px.a && xn.b == prof_px.b && xn.c == prof_px.c) || (xn.a == x.a && xn.b == x.b && xn.c == x.c);
@@ -627,6 +645,7 @@ template <class P> ADMM_HD double mt_linesearch(const P &prob, const V3 &x, cons
         if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
         if ((f <= ftest1) & (fabs(dg) <= gtol * (-dginit))) info = 1;
         if (info != 0) return stp;
+        ADMM_PROF_REGION(9);      // ... that goes on to a step selection (mt_cstep)
         if (stage1 & (f <= ftest1) & (dg >= smin(ftol, gtol) * dginit)) stage1 = false;
         // modified function in stage 1 (:118-138): one cstep call on selected operands (see mt_cstep)
         // (fx, fy, dgx, dgy are modified IN PLACE around the call -- the reference's fxm = fx - stx * dgtest ... fx = fxm + stx * dgtest on
@@ -676,11 +695,13 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
     int maxiter = maxIter;
     double new_hess_guess = 1.0;
     for (int k = 0; k < maxiter; k++) {
+        ADMM_PROF_REGION(6);      // an L-BFGS outer iteration
         V3 x_old = x0, grad_old = grad, q = grad;
         globIter++;
         const int iter = m_ < k ? m_ : k;
 #pragma unroll 1
         for (int i = iter - 1; i >= 0; --i) {
+            ADMM_PROF_REGION(7);      // a history pair in the two-loop recursion (either loop)
             V3 si, yi; si.a = hs[i][0]; si.b = hs[i][1]; si.c = hs[i][2]; yi.a = hy[i][0]; yi.b = hy[i][1]; yi.c = hy[i][2];
             const double r = 1.0 / dotd(si, yi);
             const double al = r * dotd(si, q);
@@ -690,6 +711,7 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
         q.a = gamma_k * q.a; q.b = gamma_k * q.b; q.c = gamma_k * q.c;
 #pragma unroll 1
         for (int i = 0; i < iter; ++i) {
+            ADMM_PROF_REGION(7);
             V3 si, yi; si.a = hs[i][0]; si.b = hs[i][1]; si.c = hs[i][2]; yi.a = hy[i][0]; yi.b = hy[i][1]; yi.c = hy[i][2];
             const double beta = rho[i] * dotd(q, yi);
             const double ab = alpha[i] - beta;
@@ -697,6 +719,7 @@ template <int M, class P> ADMM_HD int lbfgs_minimize(const P &prob, V3 &x0, int 
         }
         double dir = dotd(q, grad);
         if (dir < 1e-4) {
+            ADMM_PROF_REGION(14);
             q = grad;
             maxiter -= k;
             k = 0;

@@ -23,7 +23,7 @@ pkg = load_package()
 s = pkg.make_bar_system(*%r, device_id=0)
 s.initialize()
 lib = pkg.lib()
-buf = (ctypes.c_ulonglong * 96)()
+buf = (ctypes.c_ulonglong * 128)()
 frames = %d
 for f in range(frames):
     s.step(20)
@@ -43,6 +43,11 @@ for f in range(frames):
     h = v[32:64]; hw = v[64:96]
     print("   line-search evaluations per tet (%%):   " + " ".join("%%d:%%.1f" %% (k, 100 * h[k] / max(h.sum(), 1)) for k in range(32) if h[k]))
     print("   wave maximum of the same (%%):          " + " ".join("%%d:%%.1f" %% (k, 100 * hw[k] / max(hw.sum(), 1)) for k in range(32) if hw[k]))
+    rg = v[96:128]; w = max(rg[0], 1)
+    print("   region executions per WAVE (a wave issues a region once whatever its lane count): Jacobi sweeps %%.2f, rotations %%.2f, L-BFGS outer iterations %%.2f, history pairs %%.2f, "
+          "line-search evaluations %%.2f (of which %%.2f go on to a step selection), log table branch %%.2f, log near-1 branch %%.2f, L-BFGS restarts %%.3f" %% (
+              rg[1] / w, rg[2] / w, rg[6] / w, rg[7] / w, rg[8] / w, rg[9] / w, rg[10] / w, rg[11] / w, rg[14] / w))
+    print("   REGIONS " + " ".join("%%d:%%.4f" %% (k, rg[k] / w) for k in range(32) if rg[k]))
 '''
 
 
