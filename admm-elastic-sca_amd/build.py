@@ -1,8 +1,11 @@
 """Builds libadmm_hip.so in-tree (admm-elastic-sca_amd/libadmm_hip.so).
 
-  dense.cpp, factor.cpp : host-side factorization, g++ -O3 -fopenmp
-  admm_hip.hip          : kernels + C ABI, hipcc --offload-arch=gfx950,
-                          -ffp-contract=off (operation order = reference's)
+  dense.cpp, factor.cpp                  : host-side ordering / multifrontal factorization, g++ -O3 -fopenmp
+  host_setup.cpp, partition.cpp, comm.cpp : host-only parts of the library around the context (ctx.hpp): assembly + factor set-up,
+                                           subtree sharding, RCCL / all-reduce hooks -- hipcc as a host compile (HIP runtime API only)
+  admm_hip.hip                           : the device translation unit: kernels (kernels_*.hpp, factor_dev.hpp), device factorization,
+                                           upload, launches, step loop, C ABI; hipcc --offload-arch=gfx950, -ffp-contract=off
+                                           (operation order = reference's)
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only
 container as well as on the GPU box.
@@ -23,6 +26,10 @@ HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wno-unknown-p
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-function", "-Wno-unused-result", "-Wno-comment", "-Wno-bitwise-instead-of-logical",
              "-mllvm", "-disable-promote-alloca-to-vector"]
+
+
+# host-only units that see the HIP runtime API (hipStream_t & co. in ctx.hpp): hipcc with no offload target
+HIPHOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-comment", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
 
 
 def _newer(src_list, target):
@@ -51,11 +58,14 @@ def build(force=False, verbose=False, extra_hip_flags=(), out=None, tag=""):
 
 def _build_locked(force, verbose, extra_hip_flags, out, tag):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc"))]
     headers += [os.path.join(HERE, "..", "include", f) for f in ("admm_hip.h", "admm_kinds.h")]
     jobs = [
         (["g++"] + HOST_FLAGS + ["-mavx2", "-mfma"], "dense.cpp", "dense.o"),
         (["g++"] + HOST_FLAGS, "factor.cpp", "factor.o"),
+        ([hipcc] + HIPHOST_FLAGS, "host_setup.cpp", "host_setup.o"),
+        ([hipcc] + HIPHOST_FLAGS, "partition.cpp", "partition.o"),
+        ([hipcc] + HIPHOST_FLAGS, "comm.cpp", "comm.o"),
         ([hipcc] + HIP_FLAGS + list(extra_hip_flags), "admm_hip.hip", "admm_hip%s.o" % tag),
     ]
     objs = []
@@ -85,7 +95,7 @@ def source_hash():
     whether the committed PMC summary was collected on the kernels it is running."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".hip", ".cpp")))
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".hip", ".cpp", ".inc")))
     files += [os.path.join(HERE, "..", "include", f) for f in ("admm_hip.h", "admm_kinds.h")]
     for f in files:
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())

@@ -13,11 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "dev_types.hpp"
 
 namespace admm_dev {
 
-constexpr int MAX_GRAV = 4;
-struct Gravity { int n; double g[MAX_GRAV][3]; };
 
 // v += dt*g (each explicit force in order, ExplicitForce.cpp:29-39);
 // x_bar = x + dt v ; Mxbar = m x_bar ; x_cur = x_bar      (System.cpp:46-48)
@@ -324,17 +323,6 @@ struct FactorDev {
     const int *cg_slot;
     const int4 *cg4;         // same lists as fixed quadruples (-1 = none; trees with <= 4 contributions per front row), or NULL
 };
-
-// One work item of a sweep launch with everything the block needs to start, in one 64-byte record
-// (one scalar load instead of an index load followed by six dependent per-supernode loads).
-struct __attribute__((aligned(16))) SweepItem {
-    int s, part;                 // supernode; 64-row tile (forward) or column chunk (backward)
-    int k, r;                    // columns, below-diagonal rows
-    int first, pad;              // first column in factor order
-    long long panel_off, front_off, slot_off, rows_off;
-    long long pad2;              // (profile build -DADMM_SWEEP_PROFILE: the workgroup's slot in the stamp buffer, -1 = none)
-};
-static_assert(sizeof(SweepItem) == 64, "SweepItem is one 64-byte record");
 
 // sum of the children's contributions that land on front row `fr` (fixed child order)
 // ---- workgroup timeline of the sweep kernels (tools/sweep_timeline.py; variant build -DADMM_SWEEP_PROFILE, never on in the shipped

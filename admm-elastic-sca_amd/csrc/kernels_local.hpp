@@ -28,16 +28,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "local_math.hpp"
+#include "dev_types.hpp"
 #include "../../include/admm_kinds.h"
 
 namespace admm_dev {
 
 // one wave per block: a finished wave's slot refills at once instead of waiting for the slowest of a block's four
 // (tet kernel 0.374 -> 0.355 ms at 1M tets against 256-thread blocks, A/B'd twice in alternation)
-#ifndef ADMM_LOCAL_BLOCK
-#define ADMM_LOCAL_BLOCK 64
-#endif
-constexpr int LOCAL_BLOCK = ADMM_LOCAL_BLOCK;
 // one wave per workgroup is built in: the tet kernels' block-level RHS pre-reduction keeps one byte per corner position (pos4),
 // a 256-entry LDS staging per block, and s_waitcnt in place of a workgroup barrier; track_block_sum is a wave butterfly
 static_assert(LOCAL_BLOCK == 64, "the local-step kernels assume one 64-lane wave per workgroup");
@@ -45,7 +42,6 @@ static_assert(LOCAL_BLOCK == 64, "the local-step kernels assume one 64-lane wave
 #define ADMM_TET_WAVES 2   // min waves per SIMD requested for the tet kernels (caps VGPRs at 512/ADMM_TET_WAVES)
 #endif
 
-struct ShapeTable { int n; int type[ADMM_MAX_SHAPES]; double par[ADMM_MAX_SHAPES][4]; };
 
 struct BatchDev {
     int n;                 // local elements (= the SoA arrays' stride)

@@ -1,0 +1,176 @@
+// partition.cpp -- subtree sharding (who owns which supernode / element) and the XCD-aware order of a level's work items.
+#include "ctx.hpp"
+
+using namespace admm_host;
+using namespace admm_lib;
+
+namespace admm_lib {
+
+// ---- subtree sharding: who owns which supernode ------------------------------------------------------
+// Split the heaviest open subtree at its root (the root joins the replicated top) until there are >= 4 open subtrees per
+// rank, then give the subtrees to the ranks largest first (LPT).  Every vertex separator is a supernode, so an element
+// whose nodes are not all in the top lies inside exactly ONE subtree plus its ancestors: it goes to that subtree's rank.
+// `owner` <- part of every supernode (-1 = top) for `parts` parts; returns the loads through `load`, counts through n_top / n_sub
+void subtree_owners(const Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub) {
+    const int ns = (int)F.sn.size(), world = parts;
+    owner.assign(ns, 0);
+    std::vector<double> weight(ns, 0.0);
+    std::vector<std::vector<int> > kids(ns);
+    for (int s = 0; s < ns; ++s) {   // postorder: children come before parents
+        weight[s] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
+        if (F.sn[s].parent >= 0) { weight[F.sn[s].parent] += weight[s]; kids[F.sn[s].parent].push_back(s); }
+    }
+    std::vector<char> top(ns, 0);
+    auto cmp = [&](int a, int b) { return weight[a] < weight[b] || (weight[a] == weight[b] && a > b); };
+    std::vector<int> open, done;
+    for (int s = 0; s < ns; ++s) if (F.sn[s].parent < 0) open.push_back(s);
+    std::make_heap(open.begin(), open.end(), cmp);
+    // LPT assignment of the current subtrees; returns max load / mean load
+    load.assign(world, 0.0);
+    std::vector<int> root_owner(ns, -2);
+    auto assign = [&]() {
+        std::vector<int> all(done); all.insert(all.end(), open.begin(), open.end());
+        std::sort(all.begin(), all.end(), [&](int a, int b) { return weight[a] > weight[b] || (weight[a] == weight[b] && a < b); });
+        std::fill(load.begin(), load.end(), 0.0); std::fill(root_owner.begin(), root_owner.end(), -2);
+        double tot = 0.0;
+        for (int s : all) { const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin()); root_owner[s] = r; load[r] += weight[s]; tot += weight[s]; }
+        return tot > 0.0 ? *std::max_element(load.begin(), load.end()) * world / tot : 1.0;
+    };
+    // every split moves a separator into the replicated top: stop as soon as there is one subtree per rank and the loads
+    // balance within 15 %, at the latest at four subtrees per rank
+    while (!open.empty()) {
+        const int have = (int)(open.size() + done.size());
+        if (have >= 4 * world || (have >= world && assign() <= 1.15)) break;
+        std::pop_heap(open.begin(), open.end(), cmp);
+        const int s = open.back(); open.pop_back();
+        if (kids[s].empty()) { done.push_back(s); continue; }
+        top[s] = 1;
+        for (int c : kids[s]) { open.push_back(c); std::push_heap(open.begin(), open.end(), cmp); }
+    }
+    assign();
+    done.insert(done.end(), open.begin(), open.end());
+    for (int s = ns - 1; s >= 0; --s) {   // parents before children
+        if (top[s]) owner[s] = -1;
+        else if (root_owner[s] != -2) owner[s] = root_owner[s];
+        else owner[s] = owner[F.sn[s].parent];
+    }
+    n_top = 0; for (int s = 0; s < ns; ++s) n_top += top[s];
+    n_sub = done.size();
+}
+
+void partition_subtrees(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size(), world = ctx->world;
+    ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
+    ctx->grp_owner.clear();
+    if (ctx->pipe > 1 && (world > 1 || ctx->dense)) { ctx->pipe = 0; ctx->groups = 1; }      // the pipeline is a one-GPU mode of the panel sweeps
+    if (!(ctx->shard_mode == 1 && world > 1) && ctx->groups > 1 && !ctx->dense) {      // concurrent groups on this GPU
+        std::vector<double> load; int nt = 0; size_t nsub = 0;
+        subtree_owners(F, ctx->groups, ctx->grp_owner, load, nt, nsub);
+        if (getenv("ADMM_HIP_VERBOSE")) {
+            fprintf(stderr, "admm_hip: %d concurrent subtree groups: %d top supernodes, %zu subtrees, load per group (1e6 entries):", ctx->groups, nt, nsub);
+            for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
+            fprintf(stderr, "\n");
+        }
+        ctx->pipe_node_group.clear(); ctx->pipe_nodes.clear();
+        if (ctx->pipe > 1 && world == 1) {      // nodes of every group (supernodes are contiguous runs of the factor order; neighbours merge)
+            ctx->pipe_node_group.assign(F.n, -1);
+            ctx->pipe_nodes.assign(ctx->pipe + 1, {});
+            std::vector<int> by_first(ns);
+            std::iota(by_first.begin(), by_first.end(), 0);
+            std::sort(by_first.begin(), by_first.end(), [&](int a, int b) { return F.sn[a].first < F.sn[b].first; });
+            for (int s : by_first) {
+                const int g = ctx->grp_owner[s], a = F.sn[s].first, e = a + F.sn[s].ncols;
+                for (int j = a; j < e; ++j) ctx->pipe_node_group[j] = g;
+                std::vector<std::pair<int, int> > &R = ctx->pipe_nodes[g < 0 ? ctx->pipe : g];
+                if (!R.empty() && R.back().second == a) R.back().second = e; else R.push_back({a, e});
+            }
+        }
+    }
+    if (ctx->shard_mode != 1 || world <= 1) return;
+    std::vector<double> load; int nt = 0; size_t nsub = 0;
+    subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
+    for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];
+    if (getenv("ADMM_HIP_VERBOSE")) {
+        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (1e6 entries):", nt, nsub);
+        for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
+        fprintf(stderr, "\n");
+    }
+}
+
+// this rank's elements of every batch
+void assign_elements(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    int64_t nloc = 0;
+    for (Batch &b : ctx->batches) {
+        b.local.clear();
+        if (ctx->shard_mode == 1 && ctx->world > 1) {
+            for (int e = 0; e < b.n_total; ++e) {
+                int owner = -1;
+                const int32_t *nd; const int nn = b.elem_nodes(e, &nd);
+                for (int c = 0; c < nn && owner < 0; ++c) owner = ctx->node_owner[F.iperm[nd[c]]];
+                if (owner < 0) owner = e % ctx->world;      // all nodes in the replicated top: any rank will do
+                if (owner == ctx->rank) b.local.push_back(e);
+            }
+        } else {   // contiguous ranges (reference order preserved inside a rank)
+            const int first = (int)((int64_t)b.n_total * ctx->rank / ctx->world), end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
+            for (int e = first; e < end; ++e) b.local.push_back(e);
+        }
+        b.grp_ptr.clear(); b.grp_blk.clear();
+        if (ctx->pipe > 1 && ctx->world == 1 && !ctx->grp_owner.empty()) {
+            // group-major: an element belongs to the group of its first node below the top (all its nodes below the top lie in ONE
+            // subtree); elements entirely inside the top are dealt round-robin.  Reference order is kept inside a group.
+            const int G = ctx->pipe;
+            std::vector<int> grp(b.local.size());
+            for (size_t el = 0; el < b.local.size(); ++el) {
+                int g = -1;
+                const int32_t *nd; const int nn = b.elem_nodes(b.local[el], &nd);
+                for (int c = 0; c < nn && g < 0; ++c) g = ctx->pipe_node_group[F.iperm[nd[c]]];
+                grp[el] = g < 0 ? (int)(b.local[el] % G) : g;
+            }
+            std::vector<int32_t> sorted; sorted.reserve(b.local.size());
+            b.grp_ptr.assign(G + 1, 0); b.grp_blk.assign(G + 1, 0);
+            for (int g = 0; g < G; ++g) {
+                for (size_t el = 0; el < b.local.size(); ++el) if (grp[el] == g) sorted.push_back(b.local[el]);
+                b.grp_ptr[g + 1] = (int)sorted.size();
+                b.grp_blk[g + 1] = b.grp_blk[g] + (b.grp_ptr[g + 1] - b.grp_ptr[g] + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK;
+            }
+            b.local.swap(sorted);
+        }
+        b.n_local = (int)b.local.size();
+        nloc += b.n_local;
+    }
+    ctx->info.n_elems_local = nloc;
+}
+
+// XCD-aware order of a level's work items.  Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i mod 8), each
+// with its own L2: in plain order the tiles of ONE supernode land on all eight, and every L2 fetches that supernode's staged
+// vector (y, contribution lists, the children's contributions / x of its rows) from HBM again.  Here every supernode of a level
+// is given to one XCD (longest first onto the least loaded) and the list is interleaved so that its items get workgroup ids of
+// that XCD; queues of unequal length are padded with empty items (k = r = 0: the kernels do nothing for them).  `group` = items
+// per workgroup (the wave-per-tile forward kernel packs several).  Levels with few supernodes keep the plain order: there every
+// XCD is needed for each of them.
+void xcd_order(std::vector<admm_dev::SweepItem> &items, int group, int min_supernodes) {
+    const int NX = 8;
+    std::vector<std::pair<int, int> > runs;      // (first item, count) per supernode; a supernode's items are consecutive
+    for (size_t i = 0; i < items.size();) { size_t j = i; while (j < items.size() && items[j].s == items[i].s) ++j; runs.push_back({(int)i, (int)(j - i)}); i = j; }
+    if ((int)runs.size() < min_supernodes) return;
+    std::vector<int> ord(runs.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return runs[a].second > runs[b].second; });
+    std::vector<std::vector<admm_dev::SweepItem> > q(NX);
+    for (int r : ord) {
+        int best = 0;
+        for (int x = 1; x < NX; ++x) if (q[x].size() < q[best].size()) best = x;
+        q[best].insert(q[best].end(), items.begin() + runs[r].first, items.begin() + runs[r].first + runs[r].second);
+    }
+    size_t len = 0;
+    for (int x = 0; x < NX; ++x) len = std::max(len, (q[x].size() + group - 1) / group * group);
+    admm_dev::SweepItem none{};
+    std::vector<admm_dev::SweepItem> out;
+    out.reserve(len * NX);
+    for (size_t g0 = 0; g0 < len; g0 += group) for (int x = 0; x < NX; ++x) for (int t = 0; t < group; ++t) out.push_back(g0 + t < q[x].size() ? q[x][g0 + t] : none);
+    items.swap(out);
+}
+
+} // namespace admm_lib

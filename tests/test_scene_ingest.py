@@ -173,12 +173,17 @@ def run_scene(pkg, tmp_path, name, frames):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 2e-5), ("bunnyexpand", 2e-4)])
+@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 1e-10), ("bunnyexpand", 1e-10)])
 def test_shipped_scene_trajectories(pkg, tmp_path, name, tol):
     """The sample scenes, loaded from their XML by the headless SimContext and stepped on the GPU, against
     the reference's SimContext + System on the same files.  windyflag without wind / plinko contain no
     iterative prox: tight.  Wind: the reference's scatter order (1e-6).  NH / StVK
-    scenes: frame-1/2 envelopes of test_oracle_golden (the reference amplifies 1-ulp differences)."""
+    scenes, frame by frame: `tol` (the rounding of another elimination order, as tight as the cloth scenes) on
+    every frame the REFERENCE agrees with itself on when its start moves by 1-3 ulps, and 20 x the reference's own
+    measured spread (tests/golden/scene_sensitivity.npz, make_golden_scene_sensitivity.py) on the frames where its
+    truncated prox amplifies last-bit differences: the armadillo's first two frames are of the first kind (spread
+    4e-15) -- a regression there cannot hide inside an envelope --, the x1.3-expanded bunny is chaotic from frame 1
+    (1e-5, 5e-5)."""
     g = golden("scene_%s.npz" % name)
     frames = g["traj"].shape[0]
     d, traj = run_scene(pkg, tmp_path, name, frames)
@@ -186,4 +191,9 @@ def test_shipped_scene_trajectories(pkg, tmp_path, name, tol):
     scale = max(1.0, np.abs(g["traj"]).max())
     err = np.abs(traj - g["traj"]).max(axis=1) / scale
     assert np.all(np.isfinite(traj))
-    assert err.max() < tol, err
+    bound = np.full(frames, tol)
+    sens = golden("scene_sensitivity.npz")
+    if name + "_env" in sens.files:
+        bound = np.maximum(bound, 20.0 * sens[name + "_env"][:frames] / scale)
+    print("scene %s: error per frame %s, bound %s" % (name, err, bound))
+    assert np.all(err < bound), (err, bound)
