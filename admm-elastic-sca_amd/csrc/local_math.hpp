@@ -525,6 +525,20 @@ ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &
     const bool c4 = !c1 & !c2 & !c3;
     info = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : 4));
     const bool bound = c1 | c3;
+#if ADMM_PROF_ON && defined(__HIP_DEVICE_COMPILE__)
+    {   // how often do all lanes of a wave that reach the step selection sit in ONE of the four cases?  (regions 16..22)
+        const unsigned long long act = __ballot(1), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3), b4 = __ballot(c4);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+            atomicAdd(&g_tet_prof[96 + 16], 1ull);
+            if (b1 == act || b2 == act || b3 == act || b4 == act) atomicAdd(&g_tet_prof[96 + 17], 1ull);
+            if (b1) atomicAdd(&g_tet_prof[96 + 18], 1ull);
+            if (b2) atomicAdd(&g_tet_prof[96 + 19], 1ull);
+            if (b3) atomicAdd(&g_tet_prof[96 + 20], 1ull);
+            if (b4) atomicAdd(&g_tet_prof[96 + 21], 1ull);
+            atomicAdd(&g_tet_prof[96 + 22], (unsigned long long)__popcll(act));
+        }
+    }
+#endif
 #ifdef ADMM_CSTEP_STATS     // tests/host_math_shim.cpp: which cases the fixtures reach
     ADMM_CSTEP_STATS[info + (brackt ? 4 : 0)]++;
 #endif

@@ -47,6 +47,9 @@ for f in range(frames):
     print("   region executions per WAVE (a wave issues a region once whatever its lane count): Jacobi sweeps %%.2f, rotations %%.2f, L-BFGS outer iterations %%.2f, history pairs %%.2f, "
           "line-search evaluations %%.2f (of which %%.2f go on to a step selection), log table branch %%.2f, log near-1 branch %%.2f, L-BFGS restarts %%.3f" %% (
               rg[1] / w, rg[2] / w, rg[6] / w, rg[7] / w, rg[8] / w, rg[9] / w, rg[10] / w, rg[11] / w, rg[14] / w))
+    if rg[16]:
+        print("   step selections (wave level): %%.2f per wave, %%.1f %%%% with every active lane in ONE case; a lane in case 1 / 2 / 3 / 4 present in %%.0f / %%.0f / %%.0f / %%.0f %%%% of them; %%.1f lanes active on average" %% (
+            rg[16] / w, 100 * rg[17] / rg[16], 100 * rg[18] / rg[16], 100 * rg[19] / rg[16], 100 * rg[20] / rg[16], 100 * rg[21] / rg[16], rg[22] / rg[16]))
     print("   REGIONS " + " ".join("%%d:%%.4f" %% (k, rg[k] / w) for k in range(32) if rg[k]))
 '''
 
