@@ -205,9 +205,11 @@ int admm_hip_set_v(admm_hip_ctx *ctx, const double *v);
 /* The frame boundary of the class API: what host/admm/System.hpp does around admm_hip_step because m_x / m_v are
  * public members a caller may read or edit between steps (System.hpp:47-49; samples/singletet.cpp:44 writes m_x).
  * upload_state is asynchronous on the context's stream (x, v or both; NULL = leave the device copy), download_state
- * returns when both vectors have arrived.  One DMA per vector straight from / into the caller's memory; the
- * reordering to the factor's node order runs on the device.  admm_hip_pin_host page-locks (on = 1) or releases
- * (on = 0) a caller buffer so that these DMAs run at full PCIe rate without a staging copy.  Systems of up to 12 288
+ * returns when both vectors have arrived.  admm_hip_pin_host page-locks (on = 1) or releases (on = 0) a caller buffer;
+ * when both vectors travel and both are page-locked, ONE kernel each way addresses them directly over PCIe (linear on the
+ * host side, the reordering to the factor's node order on the device side; ADMM_HIP_STATE_ZEROCOPY=0: one DMA per vector
+ * + reordering kernels, also the path of pageable memory).  The caller must not touch x / v between upload_state and the
+ * next synchronising call (admm_hip_download_state, admm_hip_sync): the kernel reads them asynchronously.  Systems of up to 12 288
  * nodes (ADMM_HIP_STATE_DIRECT), when both vectors travel: no DMA at all -- the vectors are copied by the host into / out of a
  * page-locked buffer of the context that the permutation kernels address directly (the DMAs' submission latency is most
  * of a small scene's frame boundary); upload_state has then read x and v when it returns.                          */

@@ -13,6 +13,8 @@ Tolerances
   * one ADMM iteration (no chaos yet): 1e-11;  multi-frame trajectories:
     20 x the reference's own 1-ulp sensitivity (fixtures).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,41 @@ def test_local_step_bit_exact(pkg, name, params):
         if name in ("TET_STVK", "TET_NH"):
             st = np.array([o.hyper_state(i)[0] for i in range(n)]); ni = np.array([o.hyper_state(i)[1] for i in range(n)])
             assert np.array_equal(g["state"], st, equal_nan=True) and np.array_equal(g["n_iters"], ni)
+
+
+@pytest.mark.parametrize("tpb", [32, 16, 8])
+@pytest.mark.parametrize("name,params", [("TET_NH", [100.0, 150.0, 5]), ("TET_STVK", [3e3, 1e3, 9])])
+def test_fewer_tets_per_wave_is_bitwise_the_same(pkg, name, params, tpb):
+    """ADMM_HIP_TPB (under-filled launches: `tpb` tets per one-wave block, the lanes beyond idle; block-level RHS pre-reduction,
+    cost order and residual partials follow the block size): u, z, the warm start and the L-BFGS iteration counts of the local
+    step are bitwise those of the 64-lane launch over several calls with carried state, and a full frame agrees to rounding
+    (the block partial sums of the right-hand side meet in another order)."""
+    n = 777
+    def run(env):
+        old = os.environ.get("ADMM_HIP_TPB")
+        if env is None: os.environ.pop("ADMM_HIP_TPB", None)
+        else: os.environ["ADMM_HIP_TPB"] = str(env)
+        try:
+            s, o, X, idx, rng = build_disjoint(pkg, name, params, n, seed=KIND[name] + 10)
+        finally:
+            if old is None: os.environ.pop("ADMM_HIP_TPB", None)
+            else: os.environ["ADMM_HIP_TPB"] = old
+        outs = []
+        for it in range(4):
+            amp = [0.0, 0.02, 0.3, 0.8][it]
+            xcur = (X + amp * rng.normal(size=X.shape)).ravel()
+            if it == 3:
+                xcur.reshape(-1, 3)[idx[::7, 0]] += 3.0
+            s.local_step_only(xcur)
+            outs.append(s.read_local(0))
+        s.step(3)
+        return outs, s.m_x.copy()
+    a, xa = run(None)
+    b, xb = run(tpb)
+    for ga, gb in zip(a, b):
+        for k in ("u", "z", "state", "n_iters"):
+            assert np.array_equal(ga[k], gb[k], equal_nan=True), (k, tpb)
+    assert np.all(np.isfinite(xb)) and np.abs(xa - xb).max() <= 1e-9 * max(1.0, np.abs(xa).max())
 
 
 @pytest.mark.parametrize("params", [[1e5, 1e5, 5], [100.0, 150.0, 5], [50.0, 80.0, 12]])

@@ -3,7 +3,7 @@
 # bench_1M_kernel_stats.csv, level_trace_1M.txt, level_trace_fake8.txt, per_rank_kernel_time_fake_world.txt, bench_mixed.json};
 # copy them into profiles/rNN/ afterwards.   usage: tools/profile_round.sh [rNN]
 cd $GRAFT_REPO_ROOT
-R=${1:-r02}
+R=${1:-r04}
 O=gpurun_out/prof
 mkdir -p $O
 export TMPDIR=/tmp
@@ -35,3 +35,6 @@ for g in 0 1; do
 done
 cat $O/per_rank_kernel_time_fake_world.txt
 bash tools/fake_world_trace.sh 8 > /dev/null 2>&1; cp gpurun_out/level_trace_fake8.txt $O/level_trace_fake8.txt
+# 6. what each RANK's local step costs with real physics: the tet kernel launched once per subtree group of the rank partition
+for G in 2 4 8; do bash tools/group_local_times.sh $G; done > $O/group_local_times.txt 2>&1
+cat $O/group_local_times.txt
