@@ -38,9 +38,14 @@ void subtree_owners(const Factor &F, int parts, std::vector<int> &owner, std::ve
     };
     // every split moves a separator into the replicated top: stop as soon as there is one subtree per rank and the loads
     // balance within 15 %, at the latest at four subtrees per rank
+    // (ADMM_HIP_SUBTREES_PER_RANK = 2 / 3 / 4: at least that many subtrees per rank before the balance test may stop the splitting -- more,
+    // smaller subtrees mix cheap and expensive regions of the mesh on every rank at the price of a larger replicated top; measured in
+    // profiles/r04/subtrees_per_rank.txt, default 1)
+    int min_per_rank = 1;
+    if (const char *e = getenv("ADMM_HIP_SUBTREES_PER_RANK")) min_per_rank = std::min(4, std::max(1, atoi(e)));
     while (!open.empty()) {
         const int have = (int)(open.size() + done.size());
-        if (have >= 4 * world || (have >= world && assign() <= 1.15)) break;
+        if (have >= 4 * world || (have >= min_per_rank * world && assign() <= 1.15)) break;
         std::pop_heap(open.begin(), open.end(), cmp);
         const int s = open.back(); open.pop_back();
         if (kids[s].empty()) { done.push_back(s); continue; }
