@@ -432,3 +432,37 @@ class Oracle(_Sys):
         U = np.zeros(9); S = np.zeros(2); V = np.zeros(4)
         lib.orc_svd32(_d(F), _d(U), _d(S), _d(V))
         return U, S, V
+
+
+def extreme_matrices(rng, n):
+    """3x3 inputs (row-major 9-vectors of D_i x in the device's row order) that walk the corners of the Jacobi SVD and the proxes: every
+    power-of-ten scale the format holds, entries 300 decades apart inside one matrix, rank 0 / 1 / 2, diagonal, permutation, symmetric
+    and antisymmetric 2x2 blocks (the t == 0 branch of real_2x2_jacobi_svd), off-diagonals at the rotation threshold, repeated
+    singular values, inverted and reflected matrices, infinities and NaNs."""
+    M = []
+    base = rng.normal(size=(n, 3, 3))
+    for k, e in enumerate([-305, -300, -200, -160, -154, -150, -100, -20, -8, 0, 8, 20, 100, 150, 154, 160, 200, 300, 305]):
+        M.append(base[k] * 10.0 ** e)
+    for k in range(40):                       # rows / columns / entries scaled by wildly different powers of ten
+        A = rng.normal(size=(3, 3))
+        if k % 3 == 0: A = A * 10.0 ** rng.uniform(-300, 0, size=(3, 1))
+        elif k % 3 == 1: A = A * 10.0 ** rng.uniform(-300, 0, size=(1, 3))
+        else: A = A * 10.0 ** rng.uniform(-160, 0, size=(3, 3))
+        M.append(A)
+    I = np.eye(3)
+    M += [np.zeros((3, 3)), I, -I, 2.5 * I, I[[1, 2, 0]], I[[2, 1, 0]], np.diag([3.0, 2.0, 1.0]), np.diag([1.0, 1.0, 1e-300]), np.diag([1e-200, 1.0, 1e200]),
+          np.diag([1.0, -1.0, 1.0]), np.diag([-2.0, -3.0, -4.0])]
+    for k in range(10):                        # rank one and rank two
+        a, b = rng.normal(size=3), rng.normal(size=3)
+        M.append(np.outer(a, b)); M.append(np.outer(a, b) + np.outer(rng.normal(size=3), rng.normal(size=3)))
+    for eps in (0.0, 1e-17, 2.2e-16, 4.5e-16, 1e-15, 1e-8, 1e-3):     # a 2x2 block at the rotation threshold, symmetric / antisymmetric / one-sided
+        for sym in (1.0, -1.0, 0.0):
+            A = np.diag([1.0, 1.0 + 1e-9, 0.5]); A[0, 1] = eps; A[1, 0] = sym * eps; M.append(A)
+            A = np.diag([1.0, -1.0, 0.5]); A[0, 1] = eps; A[1, 0] = sym * eps; M.append(A)      # t = m00 + m11 == 0
+    R = np.array([[np.cos(0.3), -np.sin(0.3), 0], [np.sin(0.3), np.cos(0.3), 0], [0, 0, 1]])
+    M += [R, R @ np.diag([2.0, 2.0, 1.0]), R @ np.diag([1.0, 1.0, 1.0]) @ R.T, -R]
+    for v in (np.inf, -np.inf, np.nan):
+        A = rng.normal(size=(3, 3)); A[1, 2] = v; M.append(A)
+    while len(M) < n:
+        M.append(rng.normal(size=(3, 3)) * 10.0 ** rng.integers(-3, 4))
+    return np.array(M[:n]).reshape(n, 9)

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from checkers import KIND, KIND_NODES, KIND_ROWS, Oracle
+from checkers import KIND, KIND_NODES, KIND_ROWS, Oracle, extreme_matrices
 from conftest import golden
 from test_host_math import hm  # noqa: F401  (fixture: the host build of local_math.hpp + this host's libm)
 from test_oracle_golden import tol
@@ -226,6 +226,40 @@ def test_golden_project_tuples(pkg, name):
             assert np.array_equal(out["n_iters"], g["n_iters"][:, c])
     if name in ("TET_STVK", "TET_NH"):
         assert np.array_equal(s.read_local(0)["state"], g["state"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name,params", [("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]), ("TET_NH", [100.0, 150.0, 5]), ("TET_STVK", [3e3, 1e3, 9]),
+                                         ("TRI_STRAIN", [100.0, 0.95, 1.05, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_FUNG", [50.0, 0.5, 2.0])])
+def test_svd_and_prox_corner_cases_bit_exact(pkg, name, params):
+    """The Jacobi SVD and the proxes on inputs at the edges of the format (checkers.extreme_matrices) fed straight into the kernels
+    (admm_hip_local_step_dx): u, z, warm start and iteration counts bit for bit the oracle's -- the round-4 kernels use the
+    compiler's sqrt / reciprocal expansions WITHOUT their rescaling and special-case wrappers where the argument's range is
+    known; this is where a wrong range assumption would show."""
+    import warnings
+    kind = KIND[name]
+    n = 256
+    rng = np.random.default_rng(77 + kind)
+    rows = KIND_ROWS[kind]; nn = KIND_NODES[kind]
+    Dx = np.ascontiguousarray(extreme_matrices(rng, n)[:, :rows])      # (triangles: the first two columns, a 3x2 matrix)
+    x_rest = np.array([0.0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1])
+    X = np.tile(x_rest.reshape(4, 3), (n, 1)) + np.repeat(np.arange(n), 4)[:, None] * np.array([3.0, 0, 0])
+    idx = np.arange(4 * n, dtype=np.int32).reshape(n, 4)[:, :nn]
+    s = pkg.System(device_id=0); s.set_timestep(0.04)
+    s.add_nodes(X.ravel(), np.ones(3 * 4 * n))
+    s.add_forces(kind, idx, params)
+    s.initialize()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s.local_step_dx(0, Dx)
+        out = s.read_local(0)
+        for e in range(n):
+            o = Oracle.project_single(kind, X[4 * e:4 * e + nn].ravel(), params, Dx[e])
+            assert np.array_equal(out["z"][e], o["z"][0], equal_nan=True), (name, e, Dx[e], out["z"][e], o["z"][0])
+            assert np.array_equal(out["u"][e], o["u"][0], equal_nan=True), (name, e)
+            if name in ("TET_NH", "TET_STVK"):
+                assert np.array_equal(out["state"][e], o["state"], equal_nan=True), (name, e, Dx[e])
+            if name in ("TET_NH", "TET_STVK", "TRI_FUNG"):
+                assert out["n_iters"][e] == o["n_iters"][0], (name, e)
 
 
 def _bar_pair(pkg, kind, dims, iters):

@@ -27,6 +27,30 @@ def test_svd_bit_exact():
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,params", [("TET_LINEAR", [10.0]), ("TET_VOLUME", [100.0, 0.9, 1.1]), ("TET_NH", [100.0, 150.0, 5]), ("TET_STVK", [3e3, 1e3, 9]),
+                                         ("TRI_STRAIN", [100.0, 0.95, 1.05, 1.0]), ("TRI_AREA", [100.0, 4, 0.9, 1.1]), ("TRI_FUNG", [50.0, 0.5, 2.0])])
+def test_project_corner_cases_bit_exact(name, params):
+    """The oracle against the compiled reference on inputs at the edges of the format (checkers.extreme_matrices: every decade of scale,
+    entries 300 decades apart, rank 0 / 1 / 2, 2x2 blocks at the Jacobi rotation threshold incl. t == 0, infinities, NaNs): the same
+    matrices the GPU kernels are checked on against the oracle (test_gpu_parity.py::test_svd_and_prox_corner_cases_bit_exact)."""
+    import warnings
+    kind = KIND[name]
+    rng = np.random.default_rng(77 + kind)
+    Dx = np.ascontiguousarray(checkers.extreme_matrices(rng, 256)[:, :KIND_ROWS[kind]])
+    x_rest = np.array([0.0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1])[:3 * checkers.KIND_NODES[kind]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for e in range(Dx.shape[0]):
+            X = x_rest.reshape(-1, 3) + e * np.array([3.0, 0, 0])
+            a = Ref.project_single(kind, X.ravel(), params, Dx[e]); b = Oracle.project_single(kind, X.ravel(), params, Dx[e])
+            assert np.array_equal(a["z"], b["z"], equal_nan=True), (name, e, Dx[e], a["z"], b["z"])
+            assert np.array_equal(a["u"], b["u"], equal_nan=True), (name, e)
+            if name in ("TET_NH", "TET_STVK"):
+                assert np.array_equal(a["state"], b["state"], equal_nan=True), (name, e)
+            if name in ("TET_NH", "TET_STVK", "TRI_FUNG"):
+                assert np.array_equal(a["n_iters"], b["n_iters"]), (name, e)
+
+
 CASES = [("TET_NH", [1e5, 1e5, 5]), ("TET_NH", [50, 80, 20]), ("TET_STVK", [100, 100, 5]), ("TET_STVK", [3e3, 1e3, 12]), ("TET_LINEAR", [1.0]),
          ("TET_VOLUME", [100, 0.9, 1.1]), ("TRI_STRAIN", [100, .95, 1.05, 1]), ("TRI_STRAIN", [10, .5, 2, 0]), ("BEND", [20.]), ("SPRING", [50.]),
          ("ANCHOR", [55., 1]), ("TRI_AREA", [100., 4, .9, 1.1]), ("TRI_AREA", [7., 1, 1.0, 1.0]), ("TRI_FUNG", [50., 0.5, 2.0]), ("TRI_FUNG", [2e3, 0, 0])]
