@@ -135,6 +135,7 @@ def lib():
         L.admm_hip_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_keep_z.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.admm_hip_get_timing_previous.argtypes = [C.c_void_p, C.POINTER(Timing)]
         _lib = L
     return _lib
 
@@ -468,6 +469,12 @@ class System:
     def timing(self):
         t = Timing()
         self._chk(self.L.admm_hip_get_timing(self.h, C.byref(t)))
+        return t.as_dict()
+
+    def timing_previous(self):
+        """phase times of the step BEFORE the last one (read after the next step has been queued: no idle GPU between frames)"""
+        t = Timing()
+        self._chk(self.L.admm_hip_get_timing_previous(self.h, C.byref(t)))
         return t.as_dict()
 
 

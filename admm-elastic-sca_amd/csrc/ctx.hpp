@@ -223,6 +223,9 @@ struct admm_hip_ctx {
     bool timing = false; int timing_stride = 1; int ev_timed = 0; int timing_frame = 0;
     std::vector<hipEvent_t> evpool;   // recorded in order during a step, read back lazily
     size_t ev_used = 0; int ev_iters = 0; bool ev_pending = false;
+    // the step BEFORE the last one keeps its events (the two sets swap at the start of every timed step): a caller that reads them
+    // through admm_hip_get_timing_previous after queueing the next step never makes the GPU wait for the host (bench.py)
+    std::vector<hipEvent_t> evpool_prev; size_t ev_used_prev = 0; int ev_iters_prev = 0, ev_timed_prev = 0; bool ev_pending_prev = false;
     admm_hip_timing last_timing{};
 };
 

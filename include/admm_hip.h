@@ -291,6 +291,9 @@ typedef struct admm_hip_timing {
  * replay each where a graph exists) and the phase sums are scaled to the frame; total_ms is always the real span.      */
 int admm_hip_enable_timing(admm_hip_ctx *ctx, int on);
 int admm_hip_get_timing(admm_hip_ctx *ctx, admm_hip_timing *t);
+/* the step BEFORE the last one (each timed step keeps its events until the step after the next is recorded): read it after the next
+ * step has been queued and the GPU never waits for the host between frames.  ADMM_ERR_STATE if it was not timed / already read. */
+int admm_hip_get_timing_previous(admm_hip_ctx *ctx, admm_hip_timing *t);
 
 /* ---- residuals and convergence-based early exit ------------------------------------------
  * The reference only DESCRIBES these (comment at System.cpp:64-65, paper Eq. 22-23):

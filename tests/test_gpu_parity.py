@@ -1180,6 +1180,32 @@ def test_state_boundary_and_sampled_timing(pkg, monkeypatch, direct):
     s.pin_host(hx, False); s.pin_host(hv, False)
 
 
+def test_timing_of_the_previous_step(pkg):
+    """admm_hip_get_timing_previous: a timed step keeps its events until the step after the next is recorded, so a loop can read frame
+    f - 1 after queueing frame f (what bench.py does: no idle GPU between frames).  Each frame is read exactly once, in order, the
+    numbers are a frame's (iters, positive span, phases inside it), a second read and an untimed predecessor are refused, and the
+    trajectory is the untimed one bit for bit."""
+    s = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"]); s.initialize()
+    ref = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"]); ref.initialize()
+    s.step(10); ref.step(10)                      # an untimed step first
+    s.enable_timing(2)
+    s.step(10); ref.step(10)
+    with pytest.raises(pkg.AdmmHipError):         # the step before the last one was not timed
+        s.timing_previous()
+    seen = []
+    for f in range(3):
+        s.step(7 + f); ref.step(7 + f)
+        seen.append(s.timing_previous())          # the step before: 10, 7, 8 iterations
+    seen.append(s.timing())                       # the last one: 9 iterations
+    assert [t["iters"] for t in seen] == [10, 7, 8, 9]
+    for t in seen:
+        phases = t["local_ms"] + t["rhs_ms"] + t["allreduce_ms"] + t["solve_fwd_ms"] + t["solve_bwd_ms"]
+        assert t["total_ms"] > 0 and 0.3 * t["total_ms"] < phases < 2.0 * t["total_ms"]
+    with pytest.raises(pkg.AdmmHipError):         # read already
+        s.timing_previous()
+    assert np.array_equal(s.m_x, ref.m_x) and np.array_equal(s.m_v, ref.m_v)
+
+
 def test_checkpoint_resume_is_bitwise(pkg):
     """The solver's state between frames is (m_x, m_v, u of every force, the hyperelastic warm start last_prox_result + init_hess):
     the reference cannot serialise it (its save() writes geometry only); through the C ABI a fresh context that
