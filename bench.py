@@ -65,7 +65,8 @@ def parse():
     p.add_argument("--shard", choices=["subtree", "contiguous"], default="subtree",
                    help="N > 1: subtree = ranks own elimination subtrees + their elements, small per-iteration exchange (default); "
                         "contiguous = element ranges, full RHS all-reduce, replicated solve")
-    p.add_argument("--timing-stride", type=int, default=4, help="HIP events around every k-th ADMM iteration of the timed region (1 = every iteration, all launches eager)")
+    p.add_argument("--timing-stride", type=int, default=10, help="HIP events around every k-th ADMM iteration of the timed region (1 = every iteration, all launches eager); "
+                   "measured on identical frames (tools/probe/event_overhead.py): event-free 0.685-0.688 ms per iteration, k = 20 / 10: 0.690-0.693, k = 4: 0.695-0.696, k = 1: 0.71")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the class-API frame cost and the other BASELINE configs (N = 1 only)")
     p.add_argument("--cpu-dims", type=int, nargs=3, default=[16, 16, 65], help="bounded CPU-baseline sample (cubes)")
@@ -396,9 +397,9 @@ def main():
     for _ in range(a.warmup):
         s.step(ADMM_ITERS)
     sync_all()
-    # HIP events on the solver's stream around the phases of every TIMING_STRIDE-th ADMM iteration of the timed region (read
-    # back after each frame); the other iterations replay the captured graph.  An event is a barrier packet (~5 us of lost
-    # launch overlap each): around every iteration they cost 1.7 % at one GPU and ~10 % of a rank's 0.35 ms at eight.
+    # HIP events on the solver's stream around the phases of every TIMING_STRIDE-th ADMM iteration of the timed region (a frame's events
+    # are read back after the NEXT frame has been queued); the other iterations run event-free.  An event is a barrier packet (~5 us of
+    # lost launch overlap each): around every iteration they cost 3.7 % at one GPU, around every 10th 0.7 % (tools/probe/event_overhead.py).
     s.enable_timing(a.timing_stride)
     phase = dict(local_ms=0.0, rhs_ms=0.0, allreduce_ms=0.0, solve_fwd_ms=0.0, solve_bwd_ms=0.0, total_ms=0.0)
     t0 = time.perf_counter()
