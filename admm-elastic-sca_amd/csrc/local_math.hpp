@@ -514,6 +514,79 @@ template <int TYPE> struct Prox {
 // (7 divisions + 1 square root).  Every lane still performs exactly its own case's operations on its own case's operands
 // in the reference's order, so the results are bitwise those of the branching form (tests/test_host_math.py runs this
 // code on the host against the reference's cstep through the projection fixtures).
+//
+// When ALL the lanes of a wavefront that reach the selection sit in the same case (31-43 % of the wave-level calls,
+// profiles/r04/tet_phase_profile.txt) the selects buy nothing: mt_cstep_case<C> below is that one case written out -- the
+// same operations on the same operands in the same order, minus the selects (and, in case 4 with no bracket anywhere in
+// the wave, minus the whole cubic) -- and mt_cstep takes it through a wave-uniform branch.
+#ifndef ADMM_CSTEP_UNIFORM
+#define ADMM_CSTEP_UNIFORM 1
+#endif
+template <int C> ADMM_HD void mt_cstep_case(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
+                                            double fp, double dp, bool &brackt, double stpmin, double stpmax, bool any_brackt) {
+    double stpf;
+    if (C == 1) {                   // fp > fx: the minimum is bracketed (:184-206)
+        const double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma = -gamma;
+        const double gp = gamma - dx;
+        const double r = (gp + theta) / ((gp + gamma) + dp);
+        const double stpc = stx + r * (stp - stx);
+        const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.) * (stp - stx);
+        if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
+        else stpf = stpc + (stpq - stpc) / 2;
+        brackt = true;
+        sty = stp; fy = fp; dy = dp;
+    } else if (C == 2) {            // derivatives of opposite sign: bracketed (:213-234)
+        const double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma = -gamma;
+        const double gp = gamma - dp;
+        const double r = (gp + theta) / ((gp + gamma) + dx);
+        const double stpc = stp + r * (stx - stp);
+        const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+        else stpf = stpq;
+        brackt = true;
+        sty = stx; fy = fx; dy = dx;
+        stx = stp; fx = fp; dx = dp;
+    } else if (C == 3) {            // same sign, the derivative decreases in magnitude (:242-274)
+        const double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+        const double s = smax(theta, smax(dx, dp));
+        double gamma = s * sqrt(smax(0., (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        const double r = ((gamma - dp) + theta) / ((gamma + (dx - dp)) + gamma);
+        double stpc = stp + r * (stx - stp);
+        if (!((r < 0.0) & (gamma != 0.0))) stpc = (stp > stx) ? stpmax : stpmin;
+        const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        const double ac = fabs(stp - stpc), aq = fabs(stp - stpq);
+        stpf = (brackt ? (ac < aq) : (ac > aq)) ? stpc : stpq;
+        stx = stp; fx = fp; dx = dp;
+    } else {                        // same sign, the derivative does not decrease (:281-291)
+        stpf = (stp > stx) ? stpmax : stpmin;
+        if (any_brackt) {
+            const double theta = 3. * (fp - fy) / (sty - stp) + dy + dp;
+            const double s = smax(theta, smax(dy, dp));
+            double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            const double gp = gamma - dp;
+            const double r = (gp + theta) / ((gp + gamma) + dy);
+            const double stpc = stp + r * (sty - stp);
+            if (brackt) stpf = stpc;
+        }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stpf = smin(stpmax, stpf);
+    stpf = smax(stpmin, stpf);
+    stp = stpf;
+    if ((C == 1 || C == 3) && brackt) {
+        if (sty > stx) stp = smin(stx + 0.66 * (sty - stx), stp);
+        else stp = smax(stx + 0.66 * (sty - stx), stp);
+    }
+}
+
 ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp,
                       double fp, double dp, bool &brackt, double stpmin, double stpmax, int &info) {
     info = 0;
@@ -525,6 +598,15 @@ ADMM_HD void mt_cstep(double &stx, double &fx, double &dx, double &sty, double &
     const bool c4 = !c1 & !c2 & !c3;
     info = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : 4));
     const bool bound = c1 | c3;
+#if ADMM_CSTEP_UNIFORM && defined(__HIP_DEVICE_COMPILE__) && !ADMM_PROF_ON
+    {
+        const unsigned long long act = __ballot(1);
+        if (__ballot(c1) == act) { mt_cstep_case<1>(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, true); return; }
+        if (__ballot(c2) == act) { mt_cstep_case<2>(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, true); return; }
+        if (__ballot(c3) == act) { mt_cstep_case<3>(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, true); return; }
+        if (__ballot(c4) == act) { mt_cstep_case<4>(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, __ballot(brackt) != 0ull); return; }
+    }
+#endif
 #if ADMM_PROF_ON && defined(__HIP_DEVICE_COMPILE__)
     {   // how often do all lanes of a wave that reach the step selection sit in ONE of the four cases?  (regions 16..22)
         const unsigned long long act = __ballot(1), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3), b4 = __ballot(c4);

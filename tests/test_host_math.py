@@ -148,6 +148,41 @@ def test_linesearch_case_coverage(hm):
     assert all(st[4 + c] > 0 for c in (1, 2, 3, 4)), st    # and with one
 
 
+def test_cstep_one_case_form_is_bitwise_the_select_form(hm):
+    """A wave whose lanes all sit in one More-Thuente case runs that case written out (mt_cstep_case<C>) instead of the
+    select form: both must give the same bits for every input, including the degenerate ones (equal points, zero
+    slopes, infinities) where the cubic produces NaN."""
+    rng = np.random.default_rng(77)
+    n = 200000
+    a = np.zeros((n, 12))
+    stx = rng.uniform(0, 2, n) * rng.choice([0, 1, 1, 1], n)
+    stp = stx + rng.choice([-1, 1, 1, 1], n) * 10 ** rng.uniform(-6, 1, n)
+    sty = np.where(rng.uniform(size=n) < 0.5, stx, stx + rng.choice([-1, 1], n) * 10 ** rng.uniform(-6, 1, n))
+    fx = rng.normal(size=n) * 10 ** rng.uniform(-2, 4, n)
+    a[:, 0] = stx; a[:, 1] = fx
+    a[:, 2] = -np.sign(stp - stx) * 10 ** rng.uniform(-8, 4, n)                 # a descent direction seen from stx
+    a[:, 3] = sty; a[:, 4] = fx + rng.normal(size=n) * 10 ** rng.uniform(-6, 2, n); a[:, 5] = rng.normal(size=n) * 10 ** rng.uniform(-8, 4, n)
+    a[:, 6] = stp
+    a[:, 7] = fx + rng.normal(size=n) * 10 ** rng.uniform(-8, 2, n)
+    a[:, 8] = rng.normal(size=n) * 10 ** rng.uniform(-8, 4, n)
+    br = rng.uniform(size=n) < 0.5
+    a[:, 11] = br
+    a[:, 9] = np.where(br, np.minimum(stx, sty) - 1e-3, stx); a[:, 10] = np.where(br, np.maximum(stx, sty) + 10, stp + 4 * (stp - stx))
+    k = np.arange(n)
+    a[k % 97 == 0, 8] = 0.0; a[k % 89 == 0, 2] *= 0; a[k % 83 == 0, 7] = a[k % 83 == 0, 1]      # zero slopes, equal values
+    a[k % 79 == 0, 8] = a[k % 79 == 0, 2]; a[k % 73 == 0, 8] = -a[k % 73 == 0, 2]
+    a[k % 71 == 0, 7] = np.inf; a[k % 67 == 0, 8] = np.inf; a[k % 61 == 0, 7] = np.nan
+    a[k % 59 == 0, 3] = a[k % 59 == 0, 6]                                                        # sty == stp: 0 / 0 in case 4
+    a = np.ascontiguousarray(a)
+    seen = set()
+    for others in (0, 1):
+        o0 = np.zeros((n, 9)); o1 = np.zeros((n, 9))
+        hm.hm_cstep_forms(n, _p(a), others, _p(o0), _p(o1))
+        assert np.array_equal(o0.view(np.uint64), o1.view(np.uint64)), np.argwhere(o0.view(np.uint64) != o1.view(np.uint64))[:5]
+        seen |= {(int(i), int(b)) for i, b in zip(o0[:, 8], a[:, 11])}
+    assert seen >= {(c, b) for c in (1, 2, 3, 4) for b in (0, 1)}, seen
+
+
 def test_project_tet_blend(hm):
     rng = np.random.default_rng(5)
     x_rest = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.]])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/group_local_times.sh G   (GPU box) -> per-group tet kernel durations of the last frame, real physics
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; G=${1:-8}
-rm -rf /tmp/glt; (cd /tmp && ADMM_HIP_PIPE=$G rocprofv3 --kernel-trace --output-format csv -d /tmp/glt -- python3 $GRAFT_REPO_ROOT/tools/probe/group_local_times.py > /dev/null 2>&1)
+rm -rf /tmp/glt; (cd /tmp && ADMM_HIP_PIPE=$G timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/glt -- python3 $GRAFT_REPO_ROOT/tools/probe/group_local_times.py > /dev/null 2>&1)
 python3 - $G <<'PY'
 import csv, glob, sys
 G=int(sys.argv[1])

@@ -6,5 +6,5 @@ export TMPDIR=/tmp
 nx=$1; ny=$2; nz=$3; shift 3
 for v in "$@"; do export "$v"; done
 rm -rf /tmp/walk_trace
-rocprofv3 --kernel-trace -d /tmp/walk_trace -o t --output-format csv -- python3 tools/run_steps.py $nx $ny $nz 3 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace -d /tmp/walk_trace -o t --output-format csv -- python3 tools/run_steps.py $nx $ny $nz 3 > /dev/null 2>&1
 python3 tools/level_trace.py /tmp/walk_trace

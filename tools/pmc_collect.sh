@@ -10,7 +10,7 @@ groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INST
 i=0
 for g in "${groups[@]}"; do
   rm -rf /tmp/pmc_$i
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_$i -- python3 $GRAFT_REPO_ROOT/tools/$prog 1 > /tmp/pmc_$i.log 2>&1) || { echo "pass $i ($g) failed"; tail -5 /tmp/pmc_$i.log; }
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_$i -- python3 $GRAFT_REPO_ROOT/tools/$prog 1 > /tmp/pmc_$i.log 2>&1) || { echo "pass $i ($g) failed"; tail -5 /tmp/pmc_$i.log; }
   i=$((i+1))
 done
 python3 - "$dims" "${PMC_MIXED:-}" <<'PY'

@@ -6,7 +6,7 @@ groups=("SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU
 i=0
 for g in "${groups[@]}"; do
   rm -rf /tmp/im_$i
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/im_$i -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /tmp/im_$i.log 2>&1) || echo "pass $i failed"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/im_$i -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /tmp/im_$i.log 2>&1) || echo "pass $i failed"
   i=$((i+1))
 done
 python3 - <<'PY' | tee gpurun_out/tet_instmix.txt

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 i=0
 for g in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do
   rm -rf /tmp/sw_$i
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/sw_$i -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /tmp/sw_$i.log 2>&1) || { echo "pass $i ($g) failed"; tail -3 /tmp/sw_$i.log; }
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/sw_$i -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /tmp/sw_$i.log 2>&1) || { echo "pass $i ($g) failed"; tail -3 /tmp/sw_$i.log; }
   i=$((i+1))
 done
 python3 - <<'PY'

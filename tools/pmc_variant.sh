@@ -12,7 +12,7 @@ PY
 export ADMM_HIP_LIB=$GRAFT_REPO_ROOT/admm-elastic-sca_amd/_build/libadmm_hip_$name.so
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pv_$c; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pv_$c -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1
+  rm -rf /tmp/pv_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pv_$c -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv,glob

@@ -16,13 +16,13 @@ ADMM_BENCH_PMC=$R/pmc_1M.json python bench.py > $O/bench_1M.json 2> $O/bench_1M.
 tail -1 $O/bench_1M.json | cut -c1-300
 # 3. the same command under rocprofv3 --kernel-trace --stats
 rm -rf /tmp/prof_stats
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/bench_1M_under_rocprof.json 2>/dev/null)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/$O/bench_1M_under_rocprof.json 2>/dev/null)
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_1M_kernel_stats.csv
 head -14 $O/bench_1M_kernel_stats.csv | cut -c1-160
 # 4. per-level picture of one ADMM iteration (eager launches), the mixed scene
 ADMM_HIP_VERBOSE=1 python tools/run_steps.py 32 32 163 1 2>&1 | grep "admm_hip: level" > $O/level_trace_1M.txt
 rm -rf /tmp/prof_trace
-(cd /tmp && ADMM_HIP_GRAPH=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1)
+(cd /tmp && ADMM_HIP_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1)
 python tools/level_trace.py /tmp/prof_trace >> $O/level_trace_1M.txt 2>&1
 tail -12 $O/level_trace_1M.txt
 python bench.py --config mixed --no-extras > $O/bench_mixed.json 2>/dev/null
