@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
             const std::vector<int> &l = e.index_list();
             put_i(f, e.explicit_type()); put_i(f, (int)l.size());
             for (int j = 0; j < 3; ++j) put_d(f, e.direction[j]);
-            fwrite(l.data(), 4, l.size(), f);
+            if (!l.empty()) fwrite(l.data(), 4, l.size(), f);
         }
         std::string names;
         for (std::unordered_map<std::string, std::vector<mcl::Param> >::iterator it = context.scene->object_params.begin(); it != context.scene->object_params.end(); ++it) names += it->first + "\n";

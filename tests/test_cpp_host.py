@@ -22,9 +22,10 @@ BUILD = os.path.join(ROOT, "tests", "_build")
 def compile_cpp(name, pkg):
     pkg.lib()
     os.makedirs(BUILD, exist_ok=True)
-    out = os.path.join(BUILD, name)
+    extra = os.environ.get("ADMM_TEST_CXXFLAGS", "").split()      # tools/asan_host.sh: -fsanitize=address,undefined for the header-only host classes
+    out = os.path.join(BUILD, name + ("_san" if extra else ""))
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    cmd = ["g++", "-std=c++11", "-O2", "-fopenmp", "-DADMM_HOST_NO_EIGEN", "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(PKG, "host", "admm"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+    cmd = ["g++", "-std=c++11", "-O2", "-fopenmp", "-DADMM_HOST_NO_EIGEN"] + extra + [ "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(PKG, "host", "admm"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            "-L" + PKG, "-ladmm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out

@@ -36,13 +36,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def compile_scene_run(pkg):
     pkg.lib()
     os.makedirs(BUILD, exist_ok=True)
-    out = os.path.join(BUILD, "scene_run")
+    extra = os.environ.get("ADMM_TEST_CXXFLAGS", "").split()      # tools/asan_host.sh
+    out = os.path.join(BUILD, "scene_run" + ("_san" if extra else ""))
     src = os.path.join(ROOT, "tests", "cpp", "scene_run.cpp")
     hdrs = [os.path.join(PKG, "host", "SimContext.hpp"), os.path.join(PKG, "host", "MCL", "Scene.hpp"), os.path.join(PKG, "host", "admm", "System.hpp"), src]
     if os.path.exists(out) and all(os.path.getmtime(out) > os.path.getmtime(h) for h in hdrs):
         return out
     # -ffp-contract=off: the transform / mass arithmetic must round like the reference's (no FMA)
-    cmd = ["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DADMM_HOST_NO_EIGEN", "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+    cmd = ["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DADMM_HOST_NO_EIGEN"] + extra + ["-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            "-L" + PKG, "-ladmm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out
