@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: two sanity workloads beyond the benchmark -- the 4M-tet bar (64x64x163 cubes: 5 GB of panels) and an unstructured
-Delaunay mesh of ~1M NH tets (150,000 random points in a 1x1x4 box) -- ms per ADMM iteration, phases, levels."""
+"""GPU box: sanity workloads beyond the benchmark -- the 4M-tet bar (64x64x163 cubes: 5 GB of panels), on request the 16M-tet bar
+(80x80x417 cubes, `bar16m`: 64-bit offsets everywhere) and an unstructured Delaunay mesh of ~1M NH tets (150,000 random points in a
+1x1x4 box) -- ms per ADMM iteration, phases, levels, and A solve(b) = b on the bars."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -53,6 +54,21 @@ if "delaunay" in which:
     s.add_gravity((0.0, -9.8, 0.0))
     run(s, tets.shape[0], "delaunay 150k points:")
     del s
+def solve_check(s, label):
+    """|A solve(b) - b| / |b| on this system's factor (the panels' offsets pass 2^31 entries at 16M tets)"""
+    n = s.info()["n_nodes"]
+    b = np.random.default_rng(1).normal(size=(n, 3))
+    x = s.solve_only(b)
+    r = s.apply_A(x) - b.ravel()
+    print(label, "A solve(b) = b to %.2e (relative, 2-norm)" % (np.linalg.norm(r) / np.linalg.norm(b)), flush=True)
+
+
 if "bar4m" in which:
     s = pkg.make_bar_system(64, 64, 163)
     run(s, s.n_tets, "bar 64x64x163:")
+    solve_check(s, "bar 64x64x163:")
+    del s
+if "bar16m" in which:      # 16.0M tets, 2.74M nodes: more than 2^31 factor entries
+    s = pkg.make_bar_system(80, 80, 417)
+    run(s, s.n_tets, "bar 80x80x417:")
+    solve_check(s, "bar 80x80x417:")
