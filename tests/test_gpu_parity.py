@@ -1228,3 +1228,43 @@ def test_checkpoint_resume_is_bitwise(pkg):
     for _ in range(2):
         b.step(10)
     assert np.array_equal(a.m_x, b.m_x) and np.array_equal(a.m_v, b.m_v)
+
+
+def test_create_destroy_cycles_leave_no_device_memory_behind(pkg):
+    """admm_hip_destroy owns everything a context made (factor panels, batches, streams, events, captured graphs, pinned staging):
+    60 create -> initialize -> step -> destroy cycles over three kinds of scene -- sparse sweeps, the dense small-system path, a mixed
+    scene with residual tracking and timing events -- must leave the device's free memory where it was (one context of the bar below
+    holds ~40 MB, so a leaked context shows)."""
+    import gc
+    import torch
+
+    def cycle(i):
+        if i % 3 == 0:
+            s = pkg.make_bar_system(8, 8, 40)
+        elif i % 3 == 1:
+            s = pkg.make_bar_system(3, 3, 5, kind=pkg.KIND["TET_STVK"])
+        else:
+            s, _ = pkg.make_mixed_system(4, 3, 10, 8, 6)
+            s.enable_residuals(True)
+        s.initialize()
+        if i % 2:
+            s.enable_timing(1)
+        s.step(5); s.step(5)
+        if i % 2:
+            s.timing()
+        x = s.m_x.copy()
+        s.__del__()
+        return x
+
+    for i in range(6):      # warm-up: library-level caches (module load, the runtime's pools) settle
+        cycle(i)
+    gc.collect(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    first = [cycle(i) for i in range(3)]
+    for i in range(3, 60):
+        x = cycle(i)
+        if i >= 57:
+            assert np.array_equal(x, first[i % 3])      # and the 20th context of a scene computes what the first did
+    gc.collect(); torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory lost over 57 cycles: %.1f MB" % ((free0 - free1) / 2 ** 20)

@@ -17,3 +17,6 @@ LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.s
 # the header-only host classes (Comm.hpp: shared-memory all-reduce, rendezvous file; System.hpp) inside sanitized test programs
 [ $# -eq 0 ] && ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 ADMM_TEST_CXXFLAGS="-fsanitize=address,undefined -fno-omit-frame-pointer -g" \
   python3 -m pytest tests/test_cpp_host.py tests/test_scene_ingest.py -x -q -m "not gpu" -p no:cacheprovider
+rc=$?
+rm -rf $B tests/_build/*_san      # sanitized binaries are large and would travel with every gpurun snapshot
+exit $rc
