@@ -2,7 +2,8 @@
 """A/B of two BUILDS of the library on one box (GPU box): every variant is compiled with its extra hipcc flags, then the variants' child
 processes alternate `reps` times; phase times per ADMM iteration from HIP events, wall time from an event-free run, checksum of x.
 
-  python tools/probe/lib_ab.py scene=mixed|bar:32x32x163[:KIND] reps=3 "a=" "b=-DADMM_MULTI_EPL=1" ["c=..."]
+  python tools/probe/lib_ab.py scene=mixed|bar:32x32x163[:KIND] reps=3 "a=" "b=-DADMM_MULTI_EPL=1" ["c=ADMM_HIP_SOME_KNOB=0"]
+(a variant = hipcc flags, starting with '-', and / or VAR=value settings of run-time knobs for its child process)
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,13 +34,15 @@ print("wall %%.1f us/iter | local %%.1f rhs %%.1f fwd %%.1f bwd %%.1f total %%.1
 def main():
     from __graft_entry__ import load_package
     pkg = load_package()
-    scene, reps, variants = "mixed", 3, []
+    scene, reps, variants, envs = "mixed", 3, [], {}
     for a in sys.argv[1:]:
         if a.startswith("scene="): scene = a[6:]
         elif a.startswith("reps="): reps = int(a[5:])
         else:
             name, flags = a.split("=", 1)
-            variants.append((name, flags.split()))
+            toks = flags.split()
+            envs[name] = dict(t.split("=", 1) for t in toks if not t.startswith("-"))      # VAR=value tokens: the variant's environment (run-time knobs)
+            variants.append((name, [t for t in toks if t.startswith("-")]))
     libs = {}
     for name, flags in variants:
         if not flags:
@@ -50,7 +53,7 @@ def main():
         libs[name] = out
     for rep in range(reps):
         for name, _ in variants:
-            env = dict(os.environ)
+            env = dict(os.environ, **envs[name])
             if libs[name]: env["ADMM_HIP_LIB"] = libs[name]
             r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, scene=scene)], env=env, capture_output=True, text=True)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
