@@ -357,6 +357,9 @@ __device__ __forceinline__ void child_sum(const FactorDev &F, int64_t fr, const 
 #ifndef ADMM_FWD_DEPTH
 #define ADMM_FWD_DEPTH 8          // panel columns per load group in the big forward kernel
 #endif
+#ifndef ADMM_FWD_DEPTH16
+#define ADMM_FWD_DEPTH16 4        // ... with 16 waves per tile (the top levels: few, long tiles)
+#endif
 #ifndef ADMM_FWD_SMALL_DEPTH
 #define ADMM_FWD_SMALL_DEPTH 8    // same for the narrow-supernode (wave per tile) forward kernel
 #endif
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(64 * NW) void solve_fwd_big_kernel(const SweepItem 
         const int jb = c0 + wave * per;
         int je = min(jb + per, c0 + kc);
         je = row_ok ? min(je, jend) : jb;
-        constexpr int D = ADMM_FWD_DEPTH;
+        constexpr int D = NW == 16 ? ADMM_FWD_DEPTH16 : ADMM_FWD_DEPTH;
         double cur[D], nxt[D];
         if (c0 > 0) __syncthreads();
         // columns this thread did not stage ahead (k beyond one per thread; without the quadruple lists: all of them)
