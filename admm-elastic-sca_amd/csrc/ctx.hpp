@@ -194,6 +194,7 @@ struct admm_hip_ctx {
     // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
     int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
     bool tree_search = true;                       // pick the elimination tree of mid-size systems by the sweeps' cost model (ADMM_HIP_TREE_SEARCH=0: the rule-based tree)
+    bool top_bwd_needed_only = true;              // subtree sharding: the backward sweep over the replicated top skips the separators this rank never reads (ADMM_HIP_TOP_BWD_ALL=1: all of them)
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
     int fwd_small_k = 64, bwd_small_k = 64;       // levels whose widest supernode has at most this many columns: wave-per-tile forward kernel / 4 columns per wave backward
     // backward sweep, wide levels with more columns than the chip holds waves (8 x 4 x 256) but at most twice as many: two columns per wave

@@ -290,6 +290,37 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
 
 
 @pytest.mark.gpu
+def test_backward_over_the_top_only_where_a_rank_reads_it(pkg, monkeypatch):
+    """Under subtree sharding a rank runs the backward sweep of the replicated top only for the separators it reads (front rows of its
+    subtrees, nodes of its elements, their ancestors); the full x of a frame takes every top node from the lowest rank that computed it.
+    Eight shards of a deep tree: the frames are bitwise those of the runs that sweep the whole top on every rank
+    (ADMM_HIP_TOP_BWD_ALL=1), and so is the solve-only entry point."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    # long thin bars: the ranks' subtrees are slabs, a rank reads 2 of the 5 (world 8) resp. 2 - 5 of the 8 (world 6) top separators
+    # (tools/probe/top_needed_verbose.py prints the counts)
+    for world, dims in ((8, (4, 4, 120)), (6, (5, 5, 90))):
+        ref = pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"]); ref.initialize()
+        b = np.random.default_rng(3).normal(size=3 * ref.n_nodes)
+        xref = ref.solve_only(b)
+        res = {}
+        for knob in ("0", "1"):
+            monkeypatch.setenv("ADMM_HIP_TOP_BWD_ALL", knob)
+            shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world) for r in range(world)]
+            hooks = _thread_allreduce_hooks(world)
+            for r, s in enumerate(shards):
+                s.set_shard_mode("subtree"); s.set_allreduce(hooks[r]); s.initialize()
+            res[knob] = _run_sharded(shards, 2, 10, b)
+        for r in range(world):
+            assert np.abs(res["0"][r][0] - xref).max() < 1e-10 * np.abs(xref).max(), (world, r, "solve vs one rank")
+            assert np.array_equal(res["0"][r][0], res["1"][r][0]), (world, r, "solve")
+            for f in range(2):
+                assert np.array_equal(res["0"][r][1][f], res["1"][r][1][f]), (world, r, f)
+            assert np.array_equal(res["0"][r][2], res["1"][r][2])
+            assert np.array_equal(res["0"][r][1][-1], res["0"][0][1][-1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
     """Shares of >= 4096 nodes: regions up to 4/3 of a rank's share become four-way tree nodes inside the ranks' subtrees (host_factor); the

@@ -4,8 +4,8 @@
 # per-rank phase table (ms per ADMM iteration) on stdout.
 #   tools/run_scale.sh [max_ranks] [extra bench args...]     e.g. tools/run_scale.sh 8 --shard subtree
 # Expected from single-GPU measurements of one rank's launch sequence and each rank's real-physics local step (profiles/r04/
-# per_rank_kernel_time_fake_world.txt, group_local_times.txt): 0.474 / 0.371 / 0.281 ms per ADMM iteration at 2 / 4 / 8
-# ranks + one 0.55 MB all-reduce, i.e. ~1.45 / 1.85 / 2.44 x one GPU (0.686 ms) before communication; contiguous sharding ~1.3 x at 8.
+# per_rank_kernel_time_fake_world.txt, group_local_times.txt): 0.468 / 0.374 / 0.264 ms per ADMM iteration at 2 / 4 / 8
+# ranks + one 0.55 MB all-reduce, i.e. ~1.47 / 1.83 / 2.60 x one GPU (0.686 ms) before communication; contiguous sharding ~1.3 x at 8.
 cd "$(dirname "$0")/.."
 max=${1:-8}; shift
 mkdir -p gpurun_out
