@@ -41,7 +41,9 @@ class Info(C.Structure):
                                          "panel_bytes", "n_supernodes", "n_levels", "max_super_cols", "max_super_rows",
                                          "solve_contrib_rows")] + \
                [(n, C.c_double) for n in ("t_order_s", "t_symbolic_s", "t_numeric_s", "t_upload_s")] + \
-               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")] + [("rhs_slots", C.c_int64)]
+               [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")] + \
+               [(n, C.c_int64) for n in ("rhs_slots", "sweep_entries_own", "sweep_entries_top", "sweep_entries_top_bwd", "nodes_own", "nodes_top",
+                                         "comm_doubles_iter", "comm_doubles_frame")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -128,6 +130,9 @@ def lib():
         L.admm_hip_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.admm_hip_set_rccl_comm.argtypes = [C.c_void_p, C.c_void_p]
         L.admm_hip_debug_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.admm_hip_rccl_async_error.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.admm_hip_allreduce_host.argtypes = [C.c_void_p, _dp, C.c_int64]
+        L.admm_hip_debug_graph_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.admm_hip_pin_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.admm_hip_upload_state.argtypes = [C.c_void_p, _dp, _dp]
         L.admm_hip_download_state.argtypes = [C.c_void_p, _dp, _dp]
@@ -248,6 +253,23 @@ class System:
 
     def debug_allreduce(self, dev_ptr, count):
         self._chk(self.L.admm_hip_debug_allreduce(self.h, C.c_void_p(dev_ptr), int(count)))
+
+    def rccl_async_error(self):
+        """ncclCommGetAsyncError of the installed communicator: 0 while healthy (raises with RCCL's text otherwise)"""
+        r = C.c_int(0)
+        self._chk(self.L.admm_hip_rccl_async_error(self.h, C.byref(r)))
+        return r.value
+
+    def allreduce_host(self, vec):
+        """a short host vector summed in place across the ranks through the installed transport (no-op at world 1)"""
+        assert vec.dtype == np.float64 and vec.flags.c_contiguous
+        self._chk(self.L.admm_hip_allreduce_host(self.h, _d(vec), vec.size))
+        return vec
+
+    def graph_state(self):
+        a = C.c_int(0); b = C.c_int(0); n = C.c_int64(0)
+        self._chk(self.L.admm_hip_debug_graph_state(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return dict(iter_graph=bool(a.value), frame_graph_iters=b.value, graph_launches=n.value)
 
     # ---- the class API's frame boundary (host/admm/System.hpp step()) ----
     def pin_host(self, arr, on=True):

@@ -25,6 +25,7 @@ struct RcclApi {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommGetAsyncError)(void *, int *) = nullptr;      // optional: absent in very old builds
 };
 RcclApi *rccl_api(std::string *why) {
     static RcclApi api; static bool tried = false; static std::string err;
@@ -41,6 +42,7 @@ RcclApi *rccl_api(std::string *why) {
             api.CommDestroy = (int (*)(void *))dlsym(api.handle, "ncclCommDestroy");
             api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.handle, "ncclAllReduce");
             api.GetErrorString = (const char *(*)(int))dlsym(api.handle, "ncclGetErrorString");
+            api.CommGetAsyncError = (int (*)(void *, int *))dlsym(api.handle, "ncclCommGetAsyncError");
             if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce"; api.handle = nullptr; }
         }
     }
@@ -58,6 +60,20 @@ int do_allreduce(admm_hip_ctx *ctx, double *buf, int64_t count) {
     }
     if (!ctx->allreduce) return fail(ctx, ADMM_ERR_COMM, "world size %d but neither an RCCL communicator nor an all-reduce hook is installed", ctx->world);
     if (ctx->allreduce(ctx->allreduce_user, buf, count, (void *)ctx->stream) != 0) return fail(ctx, ADMM_ERR_COMM, "all-reduce hook failed");
+    return ADMM_OK;
+}
+
+// ncclCommGetAsyncError of the installed communicator (a peer that died, a failed transport): ADMM_OK while healthy / none installed
+int comm_poll(admm_hip_ctx *ctx, int *nccl_result) {
+    if (nccl_result) *nccl_result = 0;
+    if (!ctx->rccl_comm) return ADMM_OK;
+    RcclApi *R = rccl_api(nullptr);
+    if (!R || !R->CommGetAsyncError) return ADMM_OK;
+    int async = 0;
+    const int rc = R->CommGetAsyncError(ctx->rccl_comm, &async);
+    if (rc != 0) async = rc;
+    if (nccl_result) *nccl_result = async;
+    if (async != 0) return fail(ctx, ADMM_ERR_COMM, "RCCL communicator reports an asynchronous error (rank %d of %d): %s", ctx->rank, ctx->world, R->GetErrorString ? R->GetErrorString(async) : "?");
     return ADMM_OK;
 }
 
@@ -139,6 +155,10 @@ int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm) {
     if (ctx->rccl_comm && ctx->rccl_owned && R) (void)R->CommDestroy(ctx->rccl_comm);
     ctx->rccl_comm = nccl_comm; ctx->rccl_owned = false;
     return ADMM_OK;
+}
+int admm_hip_rccl_async_error(admm_hip_ctx *ctx, int *nccl_result) {
+    if (!ctx) return ADMM_ERR_ARG;
+    return comm_poll(ctx, nccl_result);
 }
 // parity / bring-up hook: sums `count` doubles of a caller-owned DEVICE buffer through the installed communicator or hook
 int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count) {

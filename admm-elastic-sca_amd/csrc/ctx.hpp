@@ -205,6 +205,7 @@ struct admm_hip_ctx {
     int xcd_min_supernodes = 16;                  // levels with at least this many supernodes get the XCD-aware item order (0 = off; ADMM_HIP_XCD)
     int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
     int fwd_nw4_kmax = 200, fwd_nw8_kmax = 400;   // forward sweep: levels whose widest supernode has at most this many columns run 4 / 8 waves per tile (ADMM_HIP_FWD_NW4 / _NW8)
+    int64_t graph_launches = 0;               // hipGraphLaunch calls so far (admm_hip_debug_graph_state)
     bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
     // residual tracking / early exit (off by default)
     bool res_on = false, res_ready = false;
@@ -264,12 +265,15 @@ inline int batch_blocks(const Batch &b) { return b.grp_blk.empty() ? (b.n_local 
 // ---- what one translation unit offers the others ----
 int do_allreduce(admm_hip_ctx *ctx, double *buf, int64_t count);                                   // comm.cpp
 void comm_release(admm_hip_ctx *ctx);
+int comm_poll(admm_hip_ctx *ctx, int *nccl_result);
 int host_assemble(admm_hip_ctx *ctx, bool reuse_rest);                                             // host_setup.cpp
 int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic);
 void element_G(int kind, const double *rest, double G[4][3], int &cols);
 int idx_stride(int kind);
 void partition_subtrees(admm_hip_ctx *ctx);                                                        // partition.cpp
 void assign_elements(admm_hip_ctx *ctx);
+void top_needs(const admm_hip_ctx *ctx, std::vector<std::vector<char> > &need, std::vector<int> &provider);
+void shard_accounting(admm_hip_ctx *ctx);
 void subtree_owners(const admm_host::Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub);
 void xcd_order(std::vector<admm_dev::SweepItem> &items, int group, int min_supernodes);
 

@@ -103,6 +103,73 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     }
 }
 
+// Subtree sharding: which top supernodes' x does a rank need?  The forward sweep over the top is complete on every rank (it sums
+// towards the root), but the backward sweep only has to reach the separators a rank touches: those that appear among the front rows
+// of its own subtrees, those its elements have a node in, and their ancestors.  Everybody evaluates the rule for EVERY rank (no
+// communication): need[r][s] per rank and supernode; provider[s] = the lowest rank that computes top supernode s (its x goes into
+// the per-frame assembly of the full vector from that rank).
+void top_needs(const admm_hip_ctx *ctx, std::vector<std::vector<char> > &need, std::vector<int> &provider) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size();
+    std::vector<int> sn_of(F.n, -1);
+    for (int s2 = 0; s2 < ns; ++s2) for (int j = 0; j < F.sn[s2].ncols; ++j) sn_of[F.sn[s2].first + j] = s2;
+    need.assign(ctx->world, std::vector<char>(ns, 0));
+    provider.assign(ns, 0);
+    if (ctx->top_bwd_needed_only) {
+        for (int s2 = 0; s2 < ns; ++s2) {
+            const int o = ctx->sn_owner[s2];
+            if (o < 0) continue;
+            for (int q = 0; q < F.sn[s2].nrows; ++q) { const int t = sn_of[F.rows[F.sn[s2].rows_off + q]]; if (ctx->sn_owner[t] < 0) need[o][t] = 1; }
+        }
+        for (const Batch &b : ctx->batches) for (int e = 0; e < b.n_total; ++e) {
+            const int32_t *nd; const int nn = b.elem_nodes(e, &nd);
+            int o = -1;
+            for (int c = 0; c < nn && o < 0; ++c) o = ctx->node_owner[F.iperm[nd[c]]];
+            if (o < 0) o = e % ctx->world;      // the rule of assign_elements
+            for (int c = 0; c < nn; ++c) { const int i = F.iperm[nd[c]]; if (ctx->node_owner[i] < 0) need[o][sn_of[i]] = 1; }
+        }
+        for (int r = 0; r < ctx->world; ++r) for (int s2 = 0; s2 < ns; ++s2)      // postorder: a supernode's parent has a larger index
+            if (need[r][s2] && F.sn[s2].parent >= 0) need[r][F.sn[s2].parent] = 1;
+    } else for (int r = 0; r < ctx->world; ++r) std::fill(need[r].begin(), need[r].end(), 1);
+    for (int s2 = 0; s2 < ns; ++s2) {
+        if (ctx->sn_owner[s2] >= 0) continue;
+        int p = -1;
+        for (int r = 0; r < ctx->world && p < 0; ++r) if (need[r][s2]) p = r;
+        if (p < 0) { p = 0; need[0][s2] = 1; }      // nobody touches it: rank 0 keeps it
+        provider[s2] = p;
+    }
+}
+
+// admm_hip_info's sharding figures: the factor entries this rank's sweeps stream (own supernodes, replicated top forward / backward),
+// its nodes, and the doubles it all-reduces per ADMM iteration and per frame -- what bench.py's N > 1 roofline is priced on
+void shard_accounting(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size();
+    admm_hip_info &I = ctx->info;
+    auto entries = [&](int s) { const Supernode &S = F.sn[s]; return (int64_t)S.ncols * (S.ncols + 1) / 2 + (int64_t)S.nrows * S.ncols; };
+    I.sweep_entries_own = I.sweep_entries_top = I.sweep_entries_top_bwd = 0; I.nodes_own = I.nodes_top = 0;
+    I.comm_doubles_iter = I.comm_doubles_frame = 0;
+    const bool subtree = ctx->shard_mode == 1 && ctx->world > 1;
+    if (!subtree) {
+        for (int s = 0; s < ns; ++s) I.sweep_entries_own += entries(s);
+        I.nodes_own = F.n;
+        if (ctx->world > 1) I.comm_doubles_iter = 3 * (int64_t)F.n;      // contiguous shards: the whole right-hand side, every iteration
+        return;
+    }
+    std::vector<std::vector<char> > need; std::vector<int> provider;
+    top_needs(ctx, need, provider);
+    int64_t slots = 0;
+    for (int s = 0; s < ns; ++s) {
+        const int o = ctx->sn_owner[s];
+        if (o == ctx->rank) { I.sweep_entries_own += entries(s); I.nodes_own += F.sn[s].ncols; }
+        else if (o < 0) { I.sweep_entries_top += entries(s); I.nodes_top += F.sn[s].ncols; if (need[ctx->rank][s]) I.sweep_entries_top_bwd += entries(s); }
+        const int par = F.sn[s].parent;
+        if (o >= 0 && par >= 0 && ctx->sn_owner[par] < 0) slots += F.sn[s].nrows;      // roots of the owned subtrees: their contribution rows feed the top
+    }
+    I.comm_doubles_iter = 3 * (I.nodes_top + slots);      // [partial RHS on the top nodes | subtree roots' contribution rows]
+    I.comm_doubles_frame = 3 * (int64_t)F.n;               // the full x, once per frame (shard_sync_x)
+}
+
 // this rank's elements of every batch
 void assign_elements(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;

@@ -272,6 +272,54 @@ def install_rccl(s, torch, dist, rank, world, local_rank):
     return seen
 
 
+class Watchdog:
+    """N > 1: a frame that makes no progress must end the run with a message, not hold the GPUs until the driver's own limit.
+    The main thread calls beat(what[, limit_s]) at every step of the protocol; a daemon thread ends the process -- a plain
+    os._exit(3), never a re-exec -- when the current phase has lasted longer than its limit, naming rank and phase (the
+    launcher then stops the other ranks and relays the non-zero code).  After the warm-up the per-frame limit is
+    max(ADMM_BENCH_FRAME_TIMEOUT_MIN [30 s], 100 x the warm-up frame time)."""
+
+    def __init__(self, rank, world, limit_s=900.0, poll_s=0.25):
+        import threading
+        self.rank, self.world, self.poll_s = rank, world, poll_s
+        self.t, self.what, self.limit, self.on = time.monotonic(), "start-up", float(limit_s), True
+        self.lock = threading.Lock()
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def beat(self, what, limit_s=None):
+        with self.lock:
+            self.t, self.what = time.monotonic(), what
+            if limit_s is not None:
+                self.limit = float(limit_s)
+
+    def stop(self):
+        with self.lock:
+            self.on = False
+
+    def _run(self):
+        while True:
+            time.sleep(self.poll_s)
+            with self.lock:
+                if not self.on:
+                    return
+                late = time.monotonic() - self.t
+                what, limit = self.what, self.limit
+            if late > limit:
+                print("bench: rank %d of %d: no progress for %.1f s in phase '%s' (limit %.1f s) -- a hung collective or kernel; "
+                      "exiting with code 3" % (self.rank, self.world, late, what, limit), file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+
+
+class _NoWatchdog:
+    def beat(self, what, limit_s=None):
+        pass
+
+    def stop(self):
+        pass
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -320,6 +368,8 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
+    wd = Watchdog(rank, world, float(os.environ.get("ADMM_BENCH_STARTUP_TIMEOUT", "900"))) if (world > 1 or os.environ.get("ADMM_BENCH_WATCHDOG") == "1") else _NoWatchdog()
+    wd.beat("process group + scene set-up")
     fake_dist = fake_world > 1 and os.environ.get("ADMM_BENCH_FAKE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or fake_dist:    # (fake_dist: a 1-rank RCCL group under torchrun whose all-reduce the fake-world run really calls -- wrong sums, real mechanics)
         import torch.distributed as dist
@@ -356,7 +406,12 @@ def main():
             def __init__(self, ptr, count):
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+        hang = {"calls": 0, "rank": int(os.environ.get("ADMM_BENCH_TEST_HANG_RANK", "-1")), "after": int(os.environ.get("ADMM_BENCH_TEST_HANG_AFTER", "0"))}
+
         def torch_hook(ptr, count, strm):
+            hang["calls"] += 1
+            if hang["rank"] == rank and hang["calls"] > hang["after"]:      # test hook (tests/test_sharding.py): this rank never reaches the collective again
+                time.sleep(1e6)
             t = holder.get(ptr)
             if t is None:
                 t = torch.as_tensor(_Ptr(ptr, count), device=torch.device("cuda", local_rank))
@@ -384,6 +439,7 @@ def main():
         if ranks_seen != (world if not fake_dist else 1):      # an N-rank launch whose collective joins fewer ranks is not an N-GPU run
             raise SystemExit("bench.py: rank %d: the all-reduce path joins %d ranks, expected %d" % (rank, ranks_seen, world))
     s.keep_z(False)      # production frames: the tet batches' z is never read back (what host/admm/System.hpp does too)
+    wd.beat("initialize (ordering, factorization, upload)")
     s.initialize()
     t_init = time.time() - t0
     info = s.info()
@@ -395,9 +451,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        s.step(ADMM_ITERS)
+    wd.beat("barrier before the warm-up", float(os.environ.get("ADMM_BENCH_WARMUP_TIMEOUT", "300")))
     sync_all()
+    t_w = time.perf_counter()
+    for f in range(a.warmup):
+        wd.beat("warm-up frame %d" % f)
+        s.step(ADMM_ITERS)
+    wd.beat("sync after the warm-up")
+    sync_all()
+    # per-frame limit of the timed region: 100 x the warm-up frame (it holds the first collective's lazy set-up and the graph capture)
+    frame_limit = max(float(os.environ.get("ADMM_BENCH_FRAME_TIMEOUT_MIN", "30")), 100.0 * (time.perf_counter() - t_w) / max(a.warmup, 1))
     # HIP events on the solver's stream around the phases of every TIMING_STRIDE-th ADMM iteration of the timed region (a frame's events
     # are read back after the NEXT frame has been queued); the other iterations run event-free.  An event is a barrier packet (~5 us of
     # lost launch overlap each): around every iteration they cost 3.7 % at one GPU, around every 10th 0.7 % (tools/probe/event_overhead.py).
@@ -405,16 +468,22 @@ def main():
     phase = dict(local_ms=0.0, rhs_ms=0.0, allreduce_ms=0.0, solve_fwd_ms=0.0, solve_bwd_ms=0.0, total_ms=0.0)
     t0 = time.perf_counter()
     for f in range(a.steps):
+        wd.beat("timed frame %d: queueing" % f, frame_limit)
         s.step(ADMM_ITERS)
         if f > 0:      # frame f - 1's events, read AFTER frame f has been queued: the GPU never waits for the host between two frames
+            wd.beat("timed frame %d: waiting for its events" % (f - 1))
             tm = s.timing_previous()
             for k in phase:
                 phase[k] += tm[k]
+    wd.beat("timed frame %d: waiting for its events" % (a.steps - 1))
     tm = s.timing()      # the last frame's (waits for its last event; positions stay on the device)
     for k in phase:
         phase[k] += tm[k]
+    wd.beat("sync + barrier after the timed region")
     sync_all()
     elapsed = time.perf_counter() - t0
+    wd.beat("results (MAX over the ranks, per-rank gather, read-back)", 300.0)
+    rccl_async = s.rccl_async_error() if (world > 1 or fake_dist) else None      # ncclCommGetAsyncError after the timed region: raises (non-zero exit) if the communicator is broken
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -429,21 +498,28 @@ def main():
     local_s = phase["local_ms"] * 1e-3 / iters_total
     fwd_s = phase["solve_fwd_ms"] * 1e-3 / iters_total
     bwd_s = phase["solve_bwd_ms"] * 1e-3 / iters_total
+    # what THIS rank streams: its own subtrees' panels + the replicated top (one rank / contiguous shards: the whole factor), from the
+    # library's own accounting (admm_hip_info.sweep_entries_*, csrc/partition.cpp shard_accounting); vectors: 72 B per node it sweeps over
+    sweep_nodes = info["nodes_own"] + info["nodes_top"]
+    fwd_bytes = 8.0 * (info["sweep_entries_own"] + info["sweep_entries_top"]) + 72.0 * sweep_nodes
+    bwd_bytes = 8.0 * (info["sweep_entries_own"] + info["sweep_entries_top_bwd"]) + 72.0 * sweep_nodes
     panel_bytes = info["nnz_L"] * 8.0 + info["n_nodes"] * 24.0 * 3
-    local_name, local_bytes = "project_tet_kernel<NH>", LOCAL_BYTES_PER_TET * (n_tets / world)
+    n_local = [int(s.local_elements(b).size) for b in range(len(s.batches))]      # this rank's elements per batch
+    n_tets_local = n_local[0] if a.config == "bar" else sum(n for (k, _), n in zip(s.batches, n_local) if k in (pkg.KIND["TET_NH"], pkg.KIND["TET_STVK"]))
+    local_name, local_bytes = "project_tet_kernel<NH>", LOCAL_BYTES_PER_TET * n_tets_local
+    local_bytes_min = LOCAL_BYTES_PER_TET_MIN * n_tets_local
     if a.config == "mixed":      # one launch for all batches (project_multi_kernel): SURVEY 8(d)'s bytes per element of every kind in the scene
         per_kind = {"TET_NH": 472.0, "TET_STVK": 472.0, "TET_LINEAR": 472.0, "TET_VOLUME": 472.0, "TRI_STRAIN": 284.0, "TRI_AREA": 284.0, "TRI_FUNG": 284.0,
                     "BEND": 368.0, "SPRING": 144.0, "ANCHOR": 124.0, "COLLISION": 124.0}
         names = {v: k for k, v in pkg.KIND.items()}
         local_name = "project_multi_kernel (the scene's whole local step: " + " + ".join("%d %s" % (n, names.get(k, str(k))) for k, n in s.batches) + ")"
-        local_bytes = sum(per_kind.get(names.get(k, ""), 472.0) * n for k, n in s.batches) / world
+        local_bytes = sum(per_kind.get(names.get(k, ""), 472.0) * n for (k, _), n in zip(s.batches, n_local))
+        local_bytes_min = local_bytes
     cands = {
         local_name: (local_bytes, local_s),
-        "solve_fwd (gather+panel kernels, all levels)": (panel_bytes, fwd_s),
-        "solve_bwd_kernel (all levels)": (panel_bytes, bwd_s),
+        "solve_fwd (gather+panel kernels, all levels)": (fwd_bytes, fwd_s),
+        "solve_bwd_kernel (all levels)": (bwd_bytes, bwd_s),
     }
-    if world > 1 and a.shard == "subtree":      # a rank streams only its own subtrees' panels + the top: no per-rank byte count is kept
-        cands = {k: v for k, v in cands.items() if k.startswith("project_")}
     dom = max(cands, key=lambda k: cands[k][1])
     by, sec = cands[dom]
     ach = by / sec / 1e9 if sec > 0 else 0.0
@@ -517,20 +593,26 @@ def main():
     # the whole ADMM iteration against the HBM roof: algorithmic bytes of every kernel of one iteration over the iteration's time
     it_s = phase["total_ms"] * 1e-3 / iters_total
     # (the RHS slots: written once by the local kernels, read once by the gather -- one per (64-tet block, node) since the block-level pre-reduction)
-    it_bytes = (LOCAL_BYTES_PER_TET + RHS_BYTES_PER_TET) * (n_tets / world) + RHS_BYTES_PER_NODE * info["n_nodes"] + 2.0 * panel_bytes
-    it_bytes_min = LOCAL_BYTES_PER_TET_MIN * (n_tets / world) + 2.0 * 24.0 * info.get("rhs_slots", 4 * n_tets) + RHS_BYTES_PER_NODE * info["n_nodes"] + 2.0 * panel_bytes
+    slots_local = info.get("rhs_slots", 4 * n_tets_local)
+    it_bytes = (LOCAL_BYTES_PER_TET + RHS_BYTES_PER_TET) * n_tets_local + RHS_BYTES_PER_NODE * sweep_nodes + fwd_bytes + bwd_bytes
+    it_bytes_min = LOCAL_BYTES_PER_TET_MIN * n_tets_local + 2.0 * 24.0 * slots_local + RHS_BYTES_PER_NODE * sweep_nodes + fwd_bytes + bwd_bytes
     iteration = None
-    if a.config == "bar" and not (world > 1 and a.shard == "subtree"):
+    if a.config == "bar":
         iteration = {"bytes": it_bytes, "ms": it_s * 1e3, "GB/s": it_bytes / it_s / 1e9 if it_s > 0 else 0.0, "frac": (it_bytes / it_s / 1e9 / HBM_PEAK_GBS) if it_s > 0 else 0.0,
                      "bytes_min": it_bytes_min, "frac_of_min_bytes": (it_bytes_min / it_s / 1e9 / HBM_PEAK_GBS) if it_s > 0 else 0.0,
                      "what": "SURVEY 8(d) algorithmic bytes -- tet kernel 472 B/tet + RHS assembly 96 B/tet + 48 B/node + the factor panels and vectors once per sweep -- over the mean "
-                             "ADMM iteration (HIP events, total_ms); bytes_min: what the round-3 kernels must move at the least (400 B/tet without z, one 24-byte slot per (64-tet block, node) "
-                             "written and read once)"}
+                             "ADMM iteration (HIP events, total_ms); bytes_min: what the kernels must move at the least (400 B/tet without z, one 24-byte slot per (64-tet block, node) "
+                             "written and read once)" + ("; N > 1: THIS rank's elements, own subtrees and the replicated top (rank 0's figures; per_rank has every rank's), "
+                             "the collective's time included in ms" if (world > 1 or fake_world > 1) else "")}
     if dom.startswith("project_multi_kernel"): bound = "valu"      # the same fp64 prox arithmetic as the tet kernel (no counter passes are kept for this scene: valu stays null)
     roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": by, "avg_launch_ms": sec * 1e3, "valu": valu,
-            "bytes_per_launch_min": (LOCAL_BYTES_PER_TET_MIN * (n_tets / world) if dom.startswith("project_tet_kernel") else by),
-            "frac_of_min_bytes": ((LOCAL_BYTES_PER_TET_MIN * (n_tets / world) if dom.startswith("project_tet_kernel") else by) / sec / 1e9 / HBM_PEAK_GBS) if sec > 0 else 0.0,
+            "bytes_per_launch_min": (local_bytes_min if dom.startswith("project_") else by),
+            "frac_of_min_bytes": ((local_bytes_min if dom.startswith("project_") else by) / sec / 1e9 / HBM_PEAK_GBS) if sec > 0 else 0.0,
+            # what the launch really moved over what it took: the counters' bytes (traffic) / this run's launch time -- an ACHIEVED rate;
+            # `achieved` above is SURVEY 8(d)'s yardstick (472 B per tet incl. the 72 B of z a production frame never stores)
+            "achieved_moved": (traffic / sec / 1e9) if (traffic and sec > 0) else None,
+            "frac_moved": (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic and sec > 0) else None,
             "valu_frac_measured_rates": (valu or {}).get("valu_frac_measured_rates"),
             "valu_frac": (valu or {}).get("valu_frac"),
             "note": ("bound = valu: the dominant kernel is limited by fp64 VALU issue / dependency latency; achieved / peak / frac keep the HBM yardstick "
@@ -565,13 +647,35 @@ def main():
                    "x_checksum": float(np.abs(xs).sum())},
         "roofline": roof,
     }
-    if world > 1:      # per-rank phase times (ms per ADMM iteration) and element counts: where the scaling goes
+    if world > 1 or fake_dist or fake_world > 1:
+        # the exchange, as the library accounts for it (admm_hip_info.comm_doubles_*): ONE collective per ADMM iteration (subtree shards: the
+        # packed top rows; contiguous: the whole right-hand side) + under subtree shards one more per frame (the full x before the velocity update)
+        out["comm"] = {"path": comm_path if (world > 1 or fake_dist) else "no-op hook (fake world)", "collectives_per_iter": 1 if info["comm_doubles_iter"] else 0,
+                       "bytes_per_collective": 8 * int(info["comm_doubles_iter"]),
+                       "collectives_per_frame_extra": 1 if info["comm_doubles_frame"] else 0, "bytes_per_frame_extra": 8 * int(info["comm_doubles_frame"]),
+                       "allreduce_ms_per_iter": phase["allreduce_ms"] / iters_total,
+                       "what": "allreduce_ms = pack + ncclAllReduce + unpack (subtree) resp. ncclAllReduce of the RHS (contiguous) between HIP events on the solver's "
+                               "stream, every %d-th iteration; it includes the wait for the slowest rank's local step.  The per-frame collective sits in the frame's epilogue." % a.timing_stride}
+        out["shard"] = {"mode": a.shard, "tets_local": n_tets_local, "nodes_own": int(info["nodes_own"]), "nodes_top": int(info["nodes_top"]),
+                        "sweep_entries_own": int(info["sweep_entries_own"]), "sweep_entries_top": int(info["sweep_entries_top"]), "sweep_entries_top_bwd": int(info["sweep_entries_top_bwd"]),
+                        "replicated_top_share_of_fwd_bytes": 8.0 * info["sweep_entries_top"] / fwd_bytes if fwd_bytes > 0 else 0.0,
+                        "replicated_top_share_of_all_entries": info["sweep_entries_top"] / float(max(info["nnz_L"], 1))}
+        out["rccl_async_error"] = rccl_async
+        out["graph_state"] = s.graph_state()
+    if fake_world > 1:
+        out["fake_world"] = fake_world      # a timing experiment: ONE rank's share of a fake_world-rank partition; sums replaced by the identity
+        out["rccl_ranks_seen"] = ranks_seen if fake_dist else None
+    if world > 1:      # per-rank phase times (ms per ADMM iteration), element counts and bytes: where the scaling goes
         keys = ["local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms", "total_ms"]
-        mine = torch.tensor([phase[k] / iters_total for k in keys] + [float(info["n_elems_local"])], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        extra = ["elements", "tets", "fwd_bytes", "bwd_bytes", "nodes_own"]
+        vals = [phase[k] / iters_total for k in keys] + [float(info["n_elems_local"]), float(n_tets_local), fwd_bytes, bwd_bytes, float(info["nodes_own"])]
+        mine = torch.tensor(vals, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         out["per_rank"] = {k: [round(float(t[i]), 4) for t in allr] for i, k in enumerate(keys)}
-        out["per_rank"]["elements"] = [int(t[len(keys)]) for t in allr]
+        for j, k in enumerate(extra):
+            out["per_rank"][k] = [int(t[len(keys) + j]) for t in allr]
+        out["per_rank_summary"] = {k: {"slowest": max(out["per_rank"][k]), "fastest": min(out["per_rank"][k])} for k in keys}
         out["rccl_ranks_seen"] = ranks_seen              # head count from a checked all-reduce through the path config.allreduce names
         out["ranks_ok"] = bool(ranks_seen == a.gpus == world)
     if rank == 0 and world == 1 and fake_world <= 1 and not a.no_extras:
@@ -631,6 +735,7 @@ def main():
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s x elements", "cores": 0, "kind": "unavailable", "sample": repr(e)}
         print(json.dumps(out))
+    wd.beat("tear-down", 300.0)
     if world > 1 or fake_dist:     # the library's RCCL communicator goes before the process group does
         torch.cuda.synchronize()
         del s
@@ -639,6 +744,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

@@ -140,11 +140,17 @@ int admm_hip_set_host_allreduce(admm_hip_ctx *ctx, admm_hip_host_allreduce_fn fn
  *   admm_hip_rccl_unique_id  rank 0: 128 bytes (ncclUniqueId) to hand to every rank by whatever means the host has
  *   admm_hip_rccl_init       every rank, collectively: ncclCommInitRank on the context's device; the library owns the communicator
  *   admm_hip_set_rccl_comm   use an ncclComm_t the caller already has (not owned; NULL = back to the hook)
- *   admm_hip_debug_allreduce one checked all-reduce of a caller-owned device buffer through whatever is installed     */
+ *   admm_hip_debug_allreduce one checked all-reduce of a caller-owned device buffer through whatever is installed
+ *   admm_hip_rccl_async_error  ncclCommGetAsyncError of the installed communicator: *nccl_result = 0 (ncclSuccess) while the
+ *                            communicator is healthy; a non-zero value also makes the call return ADMM_ERR_COMM with the RCCL
+ *                            error text in admm_hip_last_error.  admm_hip_step polls it once per frame when a communicator is
+ *                            installed, so a peer that died surfaces as a failed step instead of a silent hang in the next sync.
+ *                            No communicator installed: *nccl_result = 0, ADMM_OK.                                             */
 int admm_hip_rccl_unique_id(void *id128);
 int admm_hip_rccl_init(admm_hip_ctx *ctx, const void *id128, int rank, int world);
 int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm);
 int admm_hip_debug_allreduce(admm_hip_ctx *ctx, void *dev_buf, int64_t count);
+int admm_hip_rccl_async_error(admm_hip_ctx *ctx, int *nccl_result);
 /* A short HOST vector summed in place across the ranks through the same transport (no-op at world 1).  The class mirror uses
  * it for what the reference keeps per force object and a sharded run keeps on the owner rank only: a released MovingAnchor's
  * position, point->pos = Dx of the last project() (AnchorForce.cpp:80-83) -- owner's value, zeros elsewhere.              */
@@ -264,6 +270,10 @@ int admm_hip_debug_math(admm_hip_ctx *ctx, int op, int64_t n, const double *in, 
 int admm_hip_debug_gemm(admm_hip_ctx *ctx, int m, int n, int k, int lda, int ldb, int ldc, int flags, double alpha, double beta,
                         const double *A, int64_t size_a, const double *B, int64_t size_b, double *C, int64_t size_c);
 int admm_hip_debug_potrf_inv(admm_hip_ctx *ctx, int w, int ld, double *blk, double *out);
+/* launch mode of the last admm_hip_step (tests: "was the multi-GPU iteration really replayed as a graph?"):
+ * *iter_graph = 1 when a per-iteration HIP graph exists, *frame_graph = ADMM iterations of the whole-frame graph (0: none),
+ * *graph_launches = graph launches issued by the context so far.  Any pointer may be NULL.                               */
+int admm_hip_debug_graph_state(admm_hip_ctx *ctx, int *iter_graph, int *frame_graph, int64_t *graph_launches);
 
 typedef struct admm_hip_info {
     int64_t n_nodes, n_elems_total, n_elems_local, rows_compact;
@@ -277,6 +287,14 @@ typedef struct admm_hip_info {
     int32_t dense_solve;      /* 1: small system, solved as x = A_s^-1 b with the explicit inverse (see admm_hip_finalize) */
     int32_t device_factor;    /* 1: the numeric factorization ran on the GPU (csrc/factor_dev.hpp), 0: on the host */
     int64_t rhs_slots;        /* 24-byte slots the local kernels write and the RHS gather reads per ADMM iteration (this rank) */
+    /* sharding: what THIS rank's sweeps stream and what it exchanges (one rank / contiguous shards: own = the whole factor, top = 0).
+     * Entries are counted like nnz_L: k(k+1)/2 + r k per supernode.                                                          */
+    int64_t sweep_entries_own;      /* supernodes of this rank's own subtrees (both sweeps)                                  */
+    int64_t sweep_entries_top;      /* the replicated top of the tree (forward sweep: all of it, on every rank)              */
+    int64_t sweep_entries_top_bwd;  /* the part of the top this rank's backward sweep covers (separators it reads + ancestors) */
+    int64_t nodes_own, nodes_top;   /* nodes of the own subtrees / of the replicated top                                     */
+    int64_t comm_doubles_iter;      /* doubles summed across the ranks per ADMM iteration (one collective)                   */
+    int64_t comm_doubles_frame;     /* additionally once per frame (subtree shards: the full x before the velocity update)   */
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
 

@@ -231,6 +231,25 @@ class Ref(_Sys):
     def set_force_weight(self, i, w):
         self.lib.ref_set_force_weight(self.h, i, w)
 
+    def local_step(self, xcur, dt=0.04):
+        """ONE local step of the oracle on caller-supplied positions: Dx = D x_cur accumulated column-ascending like Eigen's
+        column-major product (System.cpp:54), then project() of every force in list order (System.cpp:57-58) on the oracle's
+        own u and warm-start state.  Returns flat (u, z) in the oracle's (compact) row layout; per force: rows
+        global_idx .. global_idx + KIND_ROWS[kind]."""
+        rr, cc, vv = self.D_triplets()
+        Dx = np.zeros(self.rows)
+        k = np.lexsort((cc, rr))
+        for r_, c_, v_ in zip(rr[k], cc[k], vv[k]):
+            Dx[r_] += v_ * xcur[c_]
+        u = self._view("u", self.rows); z = self._view("z", self.rows)
+        for i in range(self.n_forces):
+            f = self.lib.orc_get_force(self.h, i)
+            g = f.contents.global_idx; rows = KIND_ROWS[f.contents.kind]
+            d = np.ascontiguousarray(Dx[g:g + rows]); uu = np.ascontiguousarray(u[g:g + rows]); zz = np.zeros(rows)
+            self.lib.orc_force_project(f, float(dt), _d(d), _d(uu), _d(zz))
+            u[g:g + rows] = uu; z[g:g + rows] = zz
+        return u.copy(), z.copy()
+
     @classmethod
     def project_single(cls, kind, x_rest, params, Dx, u0=None, state=None, dt=0.04):
         """n_calls consecutive project() calls of one stand-alone element."""
@@ -382,6 +401,25 @@ class Oracle(_Sys):
     def hyper_state(self, i):
         f = self.force(i)
         return np.array(list(f.state)), f.n_iters
+
+    def local_step(self, xcur, dt=0.04):
+        """ONE local step of the oracle on caller-supplied positions: Dx = D x_cur accumulated column-ascending like Eigen's
+        column-major product (System.cpp:54), then project() of every force in list order (System.cpp:57-58) on the oracle's
+        own u and warm-start state.  Returns flat (u, z) in the oracle's (compact) row layout; per force: rows
+        global_idx .. global_idx + KIND_ROWS[kind]."""
+        rr, cc, vv = self.D_triplets()
+        Dx = np.zeros(self.rows)
+        k = np.lexsort((cc, rr))
+        for r_, c_, v_ in zip(rr[k], cc[k], vv[k]):
+            Dx[r_] += v_ * xcur[c_]
+        u = self._view("u", self.rows); z = self._view("z", self.rows)
+        for i in range(self.n_forces):
+            f = self.lib.orc_get_force(self.h, i)
+            g = f.contents.global_idx; rows = KIND_ROWS[f.contents.kind]
+            d = np.ascontiguousarray(Dx[g:g + rows]); uu = np.ascontiguousarray(u[g:g + rows]); zz = np.zeros(rows)
+            self.lib.orc_force_project(f, float(dt), _d(d), _d(uu), _d(zz))
+            u[g:g + rows] = uu; z[g:g + rows] = zz
+        return u.copy(), z.copy()
 
     @classmethod
     def project_single(cls, kind, x_rest, params, Dx, u0=None, state=None, dt=0.04):

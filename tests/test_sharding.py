@@ -427,6 +427,27 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert two["config"]["parallelism"].startswith("x2: elements and elimination subtrees")
     pr = two["per_rank"]                                       # per-rank phase times and element counts travel with the line
     assert len(pr["local_ms"]) == 2 and min(pr["total_ms"]) > 0 and sum(pr["elements"]) == 8 * 8 * 40 * 6 + 9 * 9
+    # ---- the N > 1 line's schema: every rank's times, bytes and counts; the exchange; the sweeps' roofline ----
+    for k in ("local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms", "total_ms", "elements", "tets", "fwd_bytes", "bwd_bytes", "nodes_own"):
+        assert len(pr[k]) == 2, k
+    assert sum(pr["tets"]) == 8 * 8 * 40 * 6
+    for k, v in two["per_rank_summary"].items():
+        assert v["slowest"] >= v["fastest"] >= 0 and v["slowest"] == max(pr[k])
+    cm, sh, inf1 = two["comm"], two["shard"], one["config"]
+    assert cm["collectives_per_iter"] == 1 and cm["collectives_per_frame_extra"] == 1 and cm["allreduce_ms_per_iter"] > 0
+    assert cm["bytes_per_frame_extra"] == 8 * 3 * 9 * 9 * 41 and 0 < cm["bytes_per_collective"] < cm["bytes_per_frame_extra"]      # the top rows only, not the whole RHS
+    assert sh["mode"] == "subtree" and sh["nodes_top"] > 0 and sh["nodes_own"] == pr["nodes_own"][0] and sum(pr["nodes_own"]) + sh["nodes_top"] == 9 * 9 * 41
+    assert sh["sweep_entries_top_bwd"] <= sh["sweep_entries_top"] and 0 < sh["replicated_top_share_of_fwd_bytes"] < 1
+    assert two["rccl_async_error"] == 0 and "graph_state" in two
+    rf = two["roofline"]
+    assert set(rf["all"]) >= {"solve_fwd (gather+panel kernels, all levels)", "solve_bwd_kernel (all levels)"}       # the sweeps keep their entries at N > 1
+    assert rf["all"]["solve_fwd (gather+panel kernels, all levels)"]["GB/s"] > 0 and rf["iteration"]["bytes"] > 0 and rf["iteration"]["frac"] > 0
+    # a rank streams less than the whole factor, and the two ranks together the whole factor + the top once more
+    whole = one["roofline"]["all"]["solve_fwd (gather+panel kernels, all levels)"]
+    assert max(pr["fwd_bytes"]) < whole["GB/s"] * whole["ms"] * 1e6 * 1.0001
+    # the N = 1 line from the same code: same schema minus the rank objects, value = frames * iters / wall * tets
+    assert "per_rank" not in one and "comm" not in one and one["n_gpus"] == 1
+    assert abs(one["value"] - 2 * 20 / (one["ms_per_step"] * 2e-3) * 8 * 8 * 40 * 6) < 1e-6 * one["value"]
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
 
@@ -459,6 +480,40 @@ def test_bench_self_launch_relays_the_childs_failure():
     assert r.returncode != 0
     assert "starting -m torch.distributed.run" in r.stderr and "needs an MI355X" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_watchdog_ends_a_stalled_process():
+    """bench.Watchdog (N > 1 runs): a phase that outlasts its limit ends the process with code 3 and a message naming rank and phase --
+    a plain exit from a daemon thread, no re-exec; a process that keeps beating, or that stopped the watchdog, is left alone."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "w = bench.Watchdog(3, 8, limit_s=30.0, poll_s=0.05)\n"
+            "for i in range(5): w.beat('frame %%d' %% i, 0.4); time.sleep(0.1)\n"
+            "mode = sys.argv[1]\n"
+            "if mode == 'stop': w.stop()\n"
+            "w.beat('timed frame 7: waiting for its events') if mode != 'stop' else None\n"
+            "time.sleep(1.5); print('survived')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code, "hang"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "survived" not in r.stdout
+    assert "rank 3 of 8" in r.stderr and "timed frame 7: waiting for its events" in r.stderr and "exiting with code 3" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code, "stop"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "survived" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_a_hung_collective_exits_nonzero():
+    """One rank of a 2-rank run never reaches the collective of a timed frame (test hook in bench.py's all-reduce hook): the watchdogs
+    end the ranks within the per-frame limit, bench.py relays a non-zero code, no JSON line, and stderr says which rank stalled where."""
+    import time
+    args = ["--steps", "2", "--warmup", "1", "--dims", "8", "8", "40", "--no-cpu-baseline"]
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5",
+               ADMM_BENCH_TEST_HANG_RANK="1", ADMM_BENCH_TEST_HANG_AFTER="30")      # warm-up frame: 20 calls + the frame's x; then the 10th iteration of timed frame 0
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "no progress for" in r.stderr and "timed frame" in r.stderr and "exiting with code 3" in r.stderr
+    assert time.time() - t < 300
 
 
 def _spring_net(n=9, h=0.1):
