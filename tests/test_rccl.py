@@ -64,16 +64,16 @@ def cycle():
     assert np.isfinite(s.m_x).all() and s.rccl_async_error() == 0
     del s                                                  # admm_hip_destroy -> comm_release -> ncclCommDestroy
 
-cycle()
+cycle(); cycle()      # (the process-wide pools of RCCL / the HIP runtime reach their size in the first two cycles: +176 MB once, measured)
+held = []
 torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]
 for _ in range(4):
     cycle()
-torch.cuda.synchronize()
-free1 = torch.cuda.mem_get_info()[0]
-leaked = free0 - free1
-print("LIFECYCLE ok; device memory after 4 more cycles: %%+d bytes" %% (-leaked))
-assert leaked < (64 << 20), leaked                         # RCCL keeps some process-wide state; a communicator's buffers must not pile up
+    torch.cuda.synchronize()
+    held.append(free0 - torch.cuda.mem_get_info()[0])
+print("LIFECYCLE ok; device memory held after 1..4 more cycles: %%s bytes" %% held)
+assert max(held) < (16 << 20) and held[-1] <= held[0] + (1 << 20), held      # nothing piles up per context / communicator
 '''
 
 STEPLOOP = PRELUDE + r'''
@@ -141,8 +141,8 @@ def _run(script_text, tmp_path, args=(), timeout=600, env=None):
 @pytest.mark.gpu
 def test_rccl_one_rank_communicator_lifecycle(tmp_path):
     """admm_hip_rccl_unique_id -> admm_hip_rccl_init(uid, 0, 1) -> admm_hip_debug_allreduce (values unchanged, bit for bit) ->
-    replace -> remove (the all-reduce then refuses) -> install again -> destroy with the context; five contexts in a row leave
-    no communicator buffers behind; ncclCommGetAsyncError reads 0 throughout."""
+    replace -> remove (the all-reduce then refuses) -> install again -> destroy with the context; six contexts in a row, the last
+    four leave no device memory behind; ncclCommGetAsyncError reads 0 throughout."""
     out = _run(LIFECYCLE, tmp_path)
     assert "LIFECYCLE ok" in out
 
