@@ -1347,6 +1347,11 @@ long orc_D_nnz(orc_system *s) { return s->nT; }
 void orc_get_D(orc_system *s, int *rows, int *cols, double *vals) {
     for (long t = 0; t < s->nT; ++t) { rows[t] = s->T[t].r; cols[t] = s->T[t].c; vals[t] = s->T[t].v; }
 }
+/* x = solver.solve(b) on a caller-supplied right-hand side (System.cpp:62) */
+void orc_solve(orc_system *s, const double *b, double *x) {
+    for (int i = 0; i < s->dof; ++i) x[i] = b[i];
+    ldl_solve(s, x);
+}
 long orc_L_nnz(orc_system *s) { return s->Lp ? s->Lp[s->dof] : 0; }
 
 void orc_set_omp_threads(int n) { if (n > 0) omp_set_num_threads(n); }

@@ -95,6 +95,7 @@ double *orc_z(orc_system *s);
 double *orc_wdiag(orc_system *s);
 long orc_D_nnz(orc_system *s);
 void orc_get_D(orc_system *s, int *rows, int *cols, double *vals); /* in push order */
+void orc_solve(orc_system *s, const double *b, double *x);   /* x = A^-1 b with the LDL^T of orc_initialize (System.cpp:62) */
 long orc_L_nnz(orc_system *s);
 void orc_set_omp_threads(int n);   /* team size of the local-step loop (bench.py cpu_baseline tries a few) */
 int orc_omp_threads(void);

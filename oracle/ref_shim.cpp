@@ -184,6 +184,16 @@ void ref_get_D(void *h, int *rows, int *cols, double *vals) {
 // nnz of the LDLT factor of the 3n x 3n system
 long ref_L_nnz(void *h) { return (long)((RefSystem *)h)->LDLT().matrixL().nestedExpression().nonZeros(); }
 
+// x = solver.solve(b): the reference's own SimplicialLDLT (AMD ordering, 3n x 3n) on a caller-supplied right-hand side
+// (System.cpp:62; SimplicialCholesky.h:153-177) -- the direct pin of the global step (tests/golden/solve_*.npz)
+void ref_solve(void *h, const double *b, double *x) {
+    RefSystem *s = (RefSystem *)h;
+    const int n = (int)s->m_x.size();
+    VectorXd bv = Eigen::Map<const VectorXd>(b, n);
+    VectorXd xv = s->LDLT().solve(bv);
+    std::memcpy(x, xv.data(), sizeof(double) * n);
+}
+
 // HyperElasticTet warm-start state (TetForce.hpp:146; cppoptlib meta.h:33; isolver.h:20)
 int ref_get_hyper_state(void *h, int i, double *state4) {
     if (FungTriangle *g = dynamic_cast<FungTriangle *>(((RefSystem *)h)->forces[i].get())) {

@@ -47,6 +47,19 @@ def have_ref():
     return os.path.exists(lib)
 
 
+def solve_rhs(seed, x0, m3):
+    """The three right-hand sides of the direct solve fixtures (tests/golden/solve_*.npz; 3n doubles each, node-major like
+    System::m_x): white noise, an M x_bar-like smooth vector (mass x displaced positions, what System.cpp:61 feeds the solver),
+    and one unit spike (a column of A^-1)."""
+    rng = np.random.default_rng(int(seed))
+    x0 = np.asarray(x0, dtype=np.float64).ravel(); m3 = np.asarray(m3, dtype=np.float64).ravel()
+    n = x0.size
+    b0 = rng.normal(size=n)
+    b1 = m3 * (x0 + 0.01 * np.sin(7.0 * x0 + 0.3 * np.arange(n)))
+    b2 = np.zeros(n); b2[int(rng.integers(0, n))] = 1.0
+    return np.stack([b0, b1, b2])
+
+
 class _Sys:
     """Common python face of oracle / reference systems."""
 
@@ -231,24 +244,14 @@ class Ref(_Sys):
     def set_force_weight(self, i, w):
         self.lib.ref_set_force_weight(self.h, i, w)
 
-    def local_step(self, xcur, dt=0.04):
-        """ONE local step of the oracle on caller-supplied positions: Dx = D x_cur accumulated column-ascending like Eigen's
-        column-major product (System.cpp:54), then project() of every force in list order (System.cpp:57-58) on the oracle's
-        own u and warm-start state.  Returns flat (u, z) in the oracle's (compact) row layout; per force: rows
-        global_idx .. global_idx + KIND_ROWS[kind]."""
-        rr, cc, vv = self.D_triplets()
-        Dx = np.zeros(self.rows)
-        k = np.lexsort((cc, rr))
-        for r_, c_, v_ in zip(rr[k], cc[k], vv[k]):
-            Dx[r_] += v_ * xcur[c_]
-        u = self._view("u", self.rows); z = self._view("z", self.rows)
-        for i in range(self.n_forces):
-            f = self.lib.orc_get_force(self.h, i)
-            g = f.contents.global_idx; rows = KIND_ROWS[f.contents.kind]
-            d = np.ascontiguousarray(Dx[g:g + rows]); uu = np.ascontiguousarray(u[g:g + rows]); zz = np.zeros(rows)
-            self.lib.orc_force_project(f, float(dt), _d(d), _d(uu), _d(zz))
-            u[g:g + rows] = uu; z[g:g + rows] = zz
-        return u.copy(), z.copy()
+    def solve(self, b):
+        """x = solver.solve(b) on the reference's own SimplicialLDLT of the 3n x 3n system (System.cpp:62,
+        SimplicialCholesky.h:153-177) -- reached through the derived-class accessor of oracle/ref_shim.cpp"""
+        b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+        assert b.size == self.dof
+        x = np.zeros_like(b)
+        self.lib.ref_solve(self.h, _d(b), _d(x))
+        return x
 
     @classmethod
     def project_single(cls, kind, x_rest, params, Dx, u0=None, state=None, dt=0.04):
@@ -401,6 +404,14 @@ class Oracle(_Sys):
     def hyper_state(self, i):
         f = self.force(i)
         return np.array(list(f.state)), f.n_iters
+
+    def solve(self, b):
+        """the oracle's LDL^T solve of the same 3n x 3n system (admm_oracle.c ldl_solve = SimplicialCholesky.h:153-177)"""
+        b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+        assert b.size == self.dof
+        x = np.zeros_like(b)
+        self.lib.orc_solve(self.h, _d(b), _d(x))
+        return x
 
     def local_step(self, xcur, dt=0.04):
         """ONE local step of the oracle on caller-supplied positions: Dx = D x_cur accumulated column-ascending like Eigen's
