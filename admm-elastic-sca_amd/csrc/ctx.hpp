@@ -193,6 +193,7 @@ struct admm_hip_ctx {
     int local_streams_max = 1, local_streams_min_elems = 16384; std::vector<hipStream_t> local_side; std::vector<hipEvent_t> local_join; hipEvent_t local_fork = nullptr;
     // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
     int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
+    std::vector<std::pair<const char *, size_t> > pinned;      // host spans page-locked through admm_hip_pin_host (the zero-copy state kernels check them)
     bool tree_search = true;                       // pick the elimination tree of mid-size systems by the sweeps' cost model (ADMM_HIP_TREE_SEARCH=0: the rule-based tree)
     bool top_bwd_needed_only = true;              // subtree sharding: the backward sweep over the replicated top skips the separators this rank never reads (ADMM_HIP_TOP_BWD_ALL=1: all of them)
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)

@@ -38,13 +38,15 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // A 64-bit tag every rank of ONE launch derives from the same environment (so that ranks never pick up the id of another job):
 // FNV-1a over whatever the launcher exports that is unique to the launch.  0 = nothing job-unique found.
 inline uint64_t launch_nonce() {
-    static const char *const keys[] = {"ADMM_HIP_JOB_TAG", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid",
-                                       "OMPI_MCA_orte_hnp_uri", "PMIX_NAMESPACE", "PMI_JOBID"};
+    // (the restart counters: a launcher that restarts a crashed group under the same port / job id gives the new attempt another nonce,
+    //  so the dead attempt's file -- should it have survived, see below -- is never taken for the new one's)
+    static const char *const keys[] = {"ADMM_HIP_JOB_TAG", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "MASTER_ADDR", "MASTER_PORT", "SLURM_JOB_ID", "SLURM_STEP_ID",
+                                       "SLURM_RESTART_COUNT", "OMPI_MCA_ess_base_jobid", "OMPI_MCA_orte_hnp_uri", "PMIX_NAMESPACE", "PMI_JOBID"};
     uint64_t h = 1469598103934665603ull; bool any = false;
     for (const char *k : keys) {
         const char *v = std::getenv(k);
         if (!v) continue;
-        if (std::strcmp(k, "MASTER_ADDR") != 0 && std::strcmp(k, "TORCHELASTIC_RUN_ID") != 0) any = true;      // (an address / the default run id "none" alone tell no two jobs apart)
+        if (std::strcmp(k, "MASTER_ADDR") != 0 && std::strcmp(k, "TORCHELASTIC_RUN_ID") != 0 && std::strstr(k, "RESTART_COUNT") == nullptr) any = true;      // (an address / the default run id "none" alone tell no two jobs apart)
         for (const char *c = k; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
         for (const char *c = v; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
     }
@@ -55,8 +57,11 @@ inline uint64_t launch_nonce() {
 // File = 8 bytes magic, 8 bytes nonce (launch_nonce() unless the caller passes one), 128 bytes id.  Rank 0 removes whatever sits
 // under the name first and creates its file exclusively (O_EXCL | O_NOFOLLOW, mode 0600: no symlink tricks in a shared /tmp),
 // under a temporary name renamed into place.  The others take a file only if it is a regular file of this user with the right
-// size, magic and nonce that was written no earlier than max_age_s before they began to wait -- a leftover of a crashed earlier
-// launch (same port, same tag) is older than that and is ignored; the wait goes on until rank 0's fresh file appears.
+// size, magic and nonce that was written no earlier than max_age_s before they began to wait (<= 0: any age) -- a leftover of a
+// crashed earlier launch (same port, same tag, same restart count) is older than that and is ignored; the wait goes on until rank 0's
+// fresh file appears.  The caller removes the file on rank 0 once the communicator exists (System.hpp setup_shard), so a leftover
+// needs a crash between publishing and joining; keep max_age_s generous (default 600 s: a rank may reach its rendezvous minutes
+// after rank 0 published -- staggered starts, a slow scene load -- and must still take the file).
 inline bool rccl_id_via_file(const std::string &path, int rank, unsigned char id[128], double timeout_s, double max_age_s, std::string *why, uint64_t nonce = 0) {
     static const unsigned char kMagic[8] = {'A', 'D', 'M', 'M', 'r', 'c', 'c', '1'};
     if (path.empty()) { if (why) *why = "no rendezvous file given"; return false; }

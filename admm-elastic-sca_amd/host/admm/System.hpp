@@ -89,7 +89,7 @@ public:
         // (admm_hip_set_host_allreduce, e.g. comm::ShmAllReduce::hook) in place across the ranks
         admm_hip_allreduce_fn allreduce; void *allreduce_user;
         admm_hip_host_allreduce_fn host_allreduce; void *host_allreduce_user;
-        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(120.0), rendezvous_max_age_s(120.0),
+        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(600.0), rendezvous_max_age_s(600.0),
                   allreduce(nullptr), allreduce_user(nullptr), host_allreduce(nullptr), host_allreduce_user(nullptr) {}
         // what a launcher exports: torchrun / torch.distributed.run (RANK, WORLD_SIZE, LOCAL_RANK), Open MPI, Slurm;
         // ADMM_HIP_RCCL_ID_FILE names the rendezvous file.  Returns the local rank (the caller's device_id), or -1 if no launcher is seen.

@@ -1182,6 +1182,52 @@ def test_state_boundary_and_sampled_timing(pkg, monkeypatch, direct):
     s.pin_host(hx, False); s.pin_host(hv, False)
 
 
+def test_state_boundary_with_a_partly_registered_vector(pkg, monkeypatch):
+    """admm_hip_pin_host takes any byte count: a vector page-locked over FEWER bytes than it holds (or whose registered span ends
+    inside it) must take the DMA path -- the zero-copy kernels would run off the end of the mapping -- and still arrive intact."""
+    monkeypatch.setenv("ADMM_HIP_STATE_DIRECT", "0")      # the large-system path (zero copy / DMA), not the small systems' staging buffer
+    s = pkg.make_bar_system(6, 5, 14, kind=KIND["TET_STVK"]); s.initialize()
+    n3 = 3 * s.n_nodes
+    page = 4096 // 8
+    buf = np.zeros(2 * n3 + 4 * page)
+    off = (-buf.ctypes.data // 8) % page                      # page-aligned start inside buf
+    hx = buf[off:off + n3]; hv = buf[off + n3 + page:off + 2 * n3 + page]
+    rng = np.random.default_rng(9)
+    hx[:] = s.m_x * (1.0 + 1e-3 * rng.normal(size=n3)); hv[:] = 1e-2 * rng.normal(size=n3)
+    x0, v0 = hx.copy(), hv.copy()
+    half = (n3 // 2 // page) * page * 8                       # whole pages, about half of the vector
+    s._chk(s.L.admm_hip_pin_host(s.h, hx.ctypes.data, half, 1))
+    s._chk(s.L.admm_hip_pin_host(s.h, hv.ctypes.data, half, 1))
+    s.upload_state(hx, hv)
+    assert np.array_equal(s.m_x, x0) and np.array_equal(s.m_v, v0)
+    hx[:] = 0.0; hv[:] = 0.0
+    s.download_state(hx, hv)
+    assert np.array_equal(hx, x0) and np.array_equal(hv, v0)
+    s._chk(s.L.admm_hip_pin_host(s.h, hx.ctypes.data, half, 0)); s._chk(s.L.admm_hip_pin_host(s.h, hv.ctypes.data, half, 0))
+    s.pin_host(hx); s.pin_host(hv)                            # the whole vectors: zero copy, same values
+    s.upload_state(hx, hv); hx[:] = 0.0; hv[:] = 0.0; s.download_state(hx, hv)
+    assert np.array_equal(hx, x0) and np.array_equal(hv, v0)
+    s.pin_host(hx, False); s.pin_host(hv, False)
+
+
+def test_timing_is_reset_by_enable_and_by_untimed_steps(pkg):
+    """enable, step, step, disable, steps, enable, step: the step before the last one was NOT timed -- admm_hip_get_timing_previous
+    must refuse instead of handing out the old stretch's events; and enable_timing itself forgets whatever was pending."""
+    s = pkg.make_bar_system(4, 4, 8, kind=KIND["TET_STVK"]); s.initialize()
+    s.enable_timing(1); s.step(4); s.step(4)
+    s.enable_timing(0)
+    for _ in range(3):
+        s.step(4)
+    s.enable_timing(1); s.step(4)
+    with pytest.raises(pkg.AdmmHipError):
+        s.timing_previous()
+    assert s.timing()["iters"] == 4
+    s.step(4); s.step(4)
+    s.enable_timing(2)                                        # a new setting: nothing is pending
+    with pytest.raises(pkg.AdmmHipError):
+        s.timing_previous()
+
+
 def test_timing_of_the_previous_step(pkg):
     """admm_hip_get_timing_previous: a timed step keeps its events until the step after the next is recorded, so a loop can read frame
     f - 1 after queueing frame f (what bench.py does: no idle GPU between frames).  Each frame is read exactly once, in order, the

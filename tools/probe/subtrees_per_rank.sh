@@ -8,7 +8,7 @@ for k in 1 2 4; do
   echo "=== ADMM_HIP_SUBTREES_PER_RANK=$k"
   for w in 4 8; do
     bash tools/group_local_times.sh $w
-    ADMM_HIP_VERBOSE=1 BENCH_TIMING_EXPERIMENT=1 ADMM_BENCH_FAKE_WORLD=$w python bench.py --no-cpu-baseline --no-extras --shard subtree --steps 3 --warmup 1 2> /tmp/sub_$k_$w.err | python3 tools/bench_summary.py "world$w-subtree-rank0"
-    grep "subtree sharding" /tmp/sub_$k_$w.err | head -1
+    ADMM_HIP_VERBOSE=1 BENCH_TIMING_EXPERIMENT=1 ADMM_BENCH_FAKE_WORLD=$w python bench.py --no-cpu-baseline --no-extras --shard subtree --steps 3 --warmup 1 2> /tmp/sub_${k}_${w}.err | python3 tools/bench_summary.py "world$w-subtree-rank0"
+    grep "subtree sharding" /tmp/sub_${k}_${w}.err | head -1
   done
 done
