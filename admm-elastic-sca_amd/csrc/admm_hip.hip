@@ -41,10 +41,6 @@ void drop_iteration_graphs(admm_hip_ctx *ctx) {
 
 void free_device(admm_hip_ctx *ctx) {
     drop_iteration_graphs(ctx);
-    for (int q = 0; q < 3; ++q) {
-        if (ctx->pipe_exec[q]) { (void)hipGraphExecDestroy(ctx->pipe_exec[q]); ctx->pipe_exec[q] = nullptr; }
-        if (ctx->pipe_graph_h[q]) { (void)hipGraphDestroy(ctx->pipe_graph_h[q]); ctx->pipe_graph_h[q] = nullptr; }
-    }
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
     for (Batch &b : ctx->batches) {
@@ -53,7 +49,7 @@ void free_device(admm_hip_ctx *ctx) {
         if (b.upd_ev) (void)hipEventDestroy(b.upd_ev);
         b.h_tg = nullptr; b.h_ac = nullptr; b.upd_ev = nullptr;
     }
-    ctx->levels.clear(); ctx->levels_side.clear(); ctx->levels_gtop.clear();
+    ctx->levels.clear(); ctx->levels_top.clear();
 }
 
 #include "dev_factorize.inc"

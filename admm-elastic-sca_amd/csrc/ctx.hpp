@@ -33,7 +33,6 @@ struct Batch {
     std::vector<double> targets;   // anchors [n_total][3]
     bool moving = false;
     std::vector<int32_t> active;   // anchors [n_total]
-    std::vector<int> grp_ptr, grp_blk;   // pipeline groups: element range / first 64-element block of every group in the (group-major) local order, [G + 1]
     double *h_tg = nullptr; int32_t *h_ac = nullptr; hipEvent_t upd_ev = nullptr;   // anchors: pinned staging of this rank's targets / flags + "last update has left it"
     // finalize
     std::vector<double> weight, rest, measure;  // [n_total], [n_total][12], [n_total]
@@ -138,38 +137,18 @@ struct admm_hip_ctx {
     int shard_mode = 0;                       // 0: contiguous element ranges + replicated solve, 1: subtrees
     std::vector<int> sn_owner, node_owner;    // -1 = top (replicated); node_owner in factor order
     std::vector<LevelDev> levels_top;         // sweep items of the top supernodes (levels = this rank's own ones)
-    // Concurrent subtree groups on ONE GPU (ADMM_HIP_GROUPS, not with subtree sharding): the elimination tree below a small top is
-    // cut into `groups` sets of independent subtrees; group 0 runs on the context's stream (levels), the others on side streams
-    // (levels_side), the top afterwards / before (levels_gtop).  One group's kernel fills the other's launch gaps and tails.
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;
     int merge_small = 0;                          // dissection regions of at most that many nodes become four-way tree nodes (ADMM_HIP_MERGE_SMALL)
     bool fuse_anchor_tail = true;                 // an anchor batch right behind a tet batch goes out in the tet launch (ADMM_HIP_FUSE_ANCHORS=0: own launch)
     bool device_factor = true, device_numeric = false;      // numeric factorization on the GPU (ADMM_HIP_FACTOR=host: on the host); what this context does
-    int groups = 1;
-    // Pipelined groups on ONE GPU (ADMM_HIP_PIPE=G, world 1): the elements and the elimination subtrees below a small top are cut
-    // into G independent groups (same partition as `groups`); group g's chain  bwd_g(k-1) -> local step_g(k) -> rhs_g(k) -> fwd_g(k)
-    // runs on its own stream and only the top of the tree joins them, so one group's latency-bound sweeps run under another
-    // group's VALU-bound local step.  The element arrays of every batch are group-major (Batch::grp_ptr); without the pipeline
-    // (timed iterations, residual tracking) the same layout is launched group after group on one stream: bitwise the same result.
     // the tet kernels' z is an output nobody reads back in a plain frame (admm_hip_read_local aside): admm_hip_keep_z(ctx, 0) -- what
     // the class mirror and the bench do -- stops storing it in admm_hip_step; the parity entry points (local_step_only / local_step_dx)
     // and residual tracking always store it.  ADMM_HIP_KEEP_Z=0 / 1 overrides.
     bool keep_z = true, keep_z_user = true;
     bool state_zero_copy = true;              // upload_state / download_state address the caller's page-locked vectors from ONE kernel each (any size; ADMM_HIP_STATE_ZEROCOPY=0: a DMA per vector + reordering kernels)
-    int tet_lds_pad = 0;                      // ADMM_HIP_TET_LDS_PAD (probes only): unused dynamic LDS per tet block, caps the waves per SIMD (160 KB per CU)
     int tet_tpb = 0;                          // ADMM_HIP_TPB: tets per one-wave block (4 / 8 / 16 / 32 / 64) for the NH / StVK batches; 0 = 64
     bool tet_prered = true;                   // ADMM_HIP_PRERED=0: one RHS slot per tet corner (the round-1/2 layout)
-    int pipe = 0; bool pipe_chain = true, pipe_graph = true; int pipe_cu_mask = 0;
-    std::vector<int> pipe_node_group;                                 // per node (factor order): group, -1 = top
-    std::vector<std::vector<std::pair<int, int> > > pipe_nodes;      // [G + 1] node ranges (factor order) of every group's subtrees; last = the top
-    std::vector<hipStream_t> pipe_local_streams;                      // optional CU-masked streams for the groups' local step (pipe_cu_mask)
-    std::vector<hipEvent_t> pipe_ev_fwd, pipe_ev_tet, pipe_ev_sw; hipEvent_t pipe_ev_top = nullptr;
-    hipGraphExec_t pipe_exec[3] = {nullptr, nullptr, nullptr}; hipGraph_t pipe_graph_h[3] = {nullptr, nullptr, nullptr};   // first / middle iteration, closing backward sweeps
-    std::vector<int> grp_owner;               // per supernode: group, -1 = top
-    std::vector<std::vector<LevelDev> > levels_side;
-    std::vector<LevelDev> levels_gtop;
-    std::vector<hipStream_t> side_streams; hipEvent_t ev_fork = nullptr; std::vector<hipEvent_t> ev_join;
     int n_comm_top = 0, n_comm_slots = 0;
     int *d_comm_top = nullptr, *d_comm_slots = nullptr; unsigned char *d_comm_mine = nullptr, *d_base_mask = nullptr, *d_keep_mask = nullptr;
     double *d_comm_buf = nullptr;
@@ -177,8 +156,9 @@ struct admm_hip_ctx {
     bool root_inverse = true;                 // roots of the elimination tree: forward + backward as one product with (L L^T)^-1 (ADMM_HIP_ROOT_INVERSE=0: two sweeps)
     int dense_max = 2048; bool dense = false; std::vector<double> Ainv; double *d_ainv = nullptr;
     // one ADMM iteration (local kernels, RHS, all sweep launches) captured as a HIP graph: one launch per iteration
-    // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used with timing events,
-    // residual tracking or sharding (the all-reduce hook runs host code inside the loop).  ADMM_HIP_GRAPH=0 disables.
+    // instead of 30-40; matters for the small shipped scenes, which are launch-bound.  Not used around timed iterations, with
+    // residual tracking or user forces, or under sharding with a host hook (ncclAllReduce inside the library is capturable:
+    // ADMM_HIP_GRAPH_COMM=1).  ADMM_HIP_GRAPH=0 disables.
     // Default (graph_forced = false): only for systems of < 100k nodes, where an iteration is ~20 short dependent kernels and the
     // host's launch work matters; at 1M tets the GPU is the limit and a replay is 0.5-2 % SLOWER than the same launches issued
     // eagerly (0.780 vs 0.766-0.775 ms per iteration, tools/graph_vs_eager.py).  ADMM_HIP_GRAPH=1 forces it, 0 disables it.
@@ -186,11 +166,7 @@ struct admm_hip_ctx {
     // the whole ADMM loop of a frame as ONE graph (one launch per frame instead of one per iteration: the ~5-9 us between two graph
     // launches are 5-15 % of an iteration on small and mid-size scenes); captured for the iteration count of the call, again when it changes
     bool frame_graph_on = true; hipGraph_t frame_graph = nullptr; hipGraphExec_t frame_exec = nullptr; int frame_iters = 0, last_step_iters = -1;
-    // local step of scenes with several large batches (tets of two materials, cloth triangles, hinges ...): the batches are independent
-    // (own elements, own slots), so every large one can get its own stream and the launches' tails overlap (ADMM_HIP_LOCAL_STREAMS=4; measured:
-    // the cross-stream dependencies cost 10-25 us each, the single launch above does better), small batches follow on the context's stream
     bool local_multi = true;                      // the whole local step in ONE launch when the scene has several batches (project_multi_kernel; ADMM_HIP_LOCAL_MULTI=0: one launch per batch)
-    int local_streams_max = 1, local_streams_min_elems = 16384; std::vector<hipStream_t> local_side; std::vector<hipEvent_t> local_join; hipEvent_t local_fork = nullptr;
     // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
     int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
     std::vector<std::pair<const char *, size_t> > pinned;      // host spans page-locked through admm_hip_pin_host (the zero-copy state kernels check them)
@@ -254,14 +230,10 @@ template <class T> int upload(admm_hip_ctx *ctx, T **p, const std::vector<T> &h)
 }
 #define TRY(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-// is local element `el` the last one of its 64-element launch block?  (blocks restart at every pipeline group's first element)
-inline bool block_end(const Batch &b, int el) {
-    int base = 0;
-    if (!b.grp_ptr.empty()) { size_t g = 0; while (g + 2 < b.grp_ptr.size() && el >= b.grp_ptr[g + 1]) ++g; base = b.grp_ptr[g]; if (el + 1 == b.grp_ptr[g + 1]) return true; }
-    return (el - base) % b.tpb == b.tpb - 1;
-}
+// is local element `el` the last one of its launch block?
+inline bool block_end(const Batch &b, int el) { return el % b.tpb == b.tpb - 1; }
 // number of launch blocks of a batch (tets: `tpb` elements per block; everything else LOCAL_BLOCK)
-inline int batch_blocks(const Batch &b) { return b.grp_blk.empty() ? (b.n_local + b.tpb - 1) / b.tpb : b.grp_blk.back(); }
+inline int batch_blocks(const Batch &b) { return (b.n_local + b.tpb - 1) / b.tpb; }
 
 // ---- what one translation unit offers the others ----
 int do_allreduce(admm_hip_ctx *ctx, double *buf, int64_t count);                                   // comm.cpp

@@ -160,7 +160,7 @@ __global__ void state_out_kernel(int n_nodes, const int *__restrict__ iperm, con
 #ifndef ADMM_RHS_UNROLL
 #define ADMM_RHS_UNROLL 1
 #endif
-// The launch covers the nodes [node0, node1): all of them, or one pipeline group's node ranges (admm_hip.hip pipe_*).
+// The launch covers the nodes [node0, node1).
 // NORM (residual tracking, one rank): the launch also leaves the sum of squares of its block's results in norm_partial[block]
 // (fixed tree order), so that |s|^2 needs no pass of its own.
 template <bool NORM = false>

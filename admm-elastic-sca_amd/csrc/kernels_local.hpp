@@ -22,9 +22,10 @@
 //   w2h2  f64 [n]           dt^2 * weight^2
 //   u, z  f64 SoA [rows][n]
 //   state f64 SoA [4][n]    (sigma warm start, L-BFGS init_hess)
-//   fslot f64 [incidences][3]  per-corner contributions, NODE-sorted: every corner
-//         writes its 24 bytes to its position in the node's incidence list
-//         (dst, int32 [n][4]), so that the RHS kernel streams contiguously.
+//   fslot f64 [slots][3]    the elements' shares of the right-hand side, summed per node by rhs_gather_kernel in fixed slot order.
+//         Tets: ONE slot per (64-tet block, node) -- the block's 256 corner shares are summed per node in LDS first (pos4 / bn_ptr /
+//         bn_end / bn_dst below); every other kind: one slot per corner (dst, int32 [n][stride]).  Rank-major
+//         (the r-th slot of node i at r * n_nodes + i) unless a few high-valence nodes would more than double the array: node-sorted then.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "local_math.hpp"
@@ -33,8 +34,8 @@
 
 namespace admm_dev {
 
-// one wave per block: a finished wave's slot refills at once instead of waiting for the slowest of a block's four
-// (tet kernel 0.374 -> 0.355 ms at 1M tets against 256-thread blocks, A/B'd twice in alternation)
+// one wave per block: a finished wave's slot refills at once instead of waiting for the slowest of a block's four (round 1: tet kernel -5 %
+// against 256-thread blocks, A/B'd twice in alternation; the kernel's current figures: DESIGN section 3)
 // one wave per workgroup is built in: the tet kernels' block-level RHS pre-reduction keeps one byte per corner position (pos4),
 // a 256-entry LDS staging per block, and s_waitcnt in place of a workgroup barrier; track_block_sum is a wave butterfly
 static_assert(LOCAL_BLOCK == 64, "the local-step kernels assume one 64-lane wave per workgroup");
@@ -45,7 +46,7 @@ static_assert(LOCAL_BLOCK == 64, "the local-step kernels assume one 64-lane wave
 
 struct BatchDev {
     int n;                 // local elements (= the SoA arrays' stride)
-    int e0, e1;            // the launch covers elements [e0, e1): the whole batch, or one pipeline group's range (admm_hip.hip pipe_*)
+    int e0, e1;            // the launch covers elements [e0, e1) (the whole batch: 0, n)
     const int *idx;        // [n][4]
     const double *rest;    // SoA [12][n]
     const double *par;     // SoA [P][n]
@@ -661,13 +662,7 @@ __global__ __launch_bounds__(LOCAL_BLOCK) void project_tri_kernel(BatchDev b, co
 // the next batch's blocks fill the slots the tail leaves.  Side streams do the same but pay 10-25 us per cross-stream dependency.
 // Same per-element arithmetic, own outputs per element: bitwise the same results.
 constexpr int MULTI_MAX = 8;
-#ifndef ADMM_MULTI_EPL
-#define ADMM_MULTI_EPL 1
-#endif
-// hinges and strain / area triangles inside the one-launch local step: elements per lane (see project_bend_block).  Two per lane were built to
-// give these latency-bound segments twice the loads in flight at the tet kinds' 2 waves per SIMD -- A/B'd as two builds, three alternations on one
-// box (profiles/r04/mixed_epl_ab.txt): local step of the mixed scene 157.8 / 156.4 / 157.6 us against 157.2 / 157.1 / 156.1 with one: no effect, so one.
-constexpr int MULTI_EPL = ADMM_MULTI_EPL;
+// (two elements per lane for the hinge / triangle segments were built and A/B'd in round 4 -- profiles/r04/mixed_epl_ab.txt: no effect -- and removed)
 enum { MK_TET_NH = 0, MK_TET_STVK, MK_TET_LINEAR, MK_TET_VOLUME, MK_ANCHOR, MK_SPRING, MK_BEND, MK_TRI_STRAIN, MK_TRI_AREA, MK_TRI_FUNG, MK_COLLISION };
 // (Tried: the segments' blocks interleaved in proportion through a workgroup -> (segment, block) table, so that the memory-bound blocks of the cheap kinds
 // share the SIMDs with the tet blocks all along the launch: local step of the mixed scene 0.178 -> 0.196 ms -- dearest first, back to back, is the better schedule.)
@@ -690,9 +685,9 @@ void project_multi_kernel(MultiBatch a, const double *__restrict__ x, const Shap
     case MK_TET_VOLUME: project_tet_block<3, 1, false>(b, x, lb, stage); break;
     case MK_ANCHOR: project_anchor_elem<false>(b, x, b.e0 + lb * LOCAL_BLOCK + threadIdx.x, lb); break;
     case MK_SPRING: project_spring_block(b, x, lb); break;
-    case MK_BEND: project_bend_block<MULTI_EPL>(b, x, lb); break;
-    case MK_TRI_STRAIN: project_tri_block<0, MULTI_EPL>(b, x, lb); break;
-    case MK_TRI_AREA: project_tri_block<1, MULTI_EPL>(b, x, lb); break;
+    case MK_BEND: project_bend_block<1>(b, x, lb); break;
+    case MK_TRI_STRAIN: project_tri_block<0, 1>(b, x, lb); break;
+    case MK_TRI_AREA: project_tri_block<1, 1>(b, x, lb); break;
     case MK_TRI_FUNG: project_tri_block<2, 1>(b, x, lb); break;
     case MK_COLLISION: project_collision_block(b, x, shapes, lb); break;
     default: break;

@@ -67,31 +67,6 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;
     const int ns = (int)F.sn.size(), world = ctx->world;
     ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
-    ctx->grp_owner.clear();
-    if (ctx->pipe > 1 && (world > 1 || ctx->dense)) { ctx->pipe = 0; ctx->groups = 1; }      // the pipeline is a one-GPU mode of the panel sweeps
-    if (!(ctx->shard_mode == 1 && world > 1) && ctx->groups > 1 && !ctx->dense) {      // concurrent groups on this GPU
-        std::vector<double> load; int nt = 0; size_t nsub = 0;
-        subtree_owners(F, ctx->groups, ctx->grp_owner, load, nt, nsub);
-        if (getenv("ADMM_HIP_VERBOSE")) {
-            fprintf(stderr, "admm_hip: %d concurrent subtree groups: %d top supernodes, %zu subtrees, load per group (1e6 entries):", ctx->groups, nt, nsub);
-            for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
-            fprintf(stderr, "\n");
-        }
-        ctx->pipe_node_group.clear(); ctx->pipe_nodes.clear();
-        if (ctx->pipe > 1 && world == 1) {      // nodes of every group (supernodes are contiguous runs of the factor order; neighbours merge)
-            ctx->pipe_node_group.assign(F.n, -1);
-            ctx->pipe_nodes.assign(ctx->pipe + 1, {});
-            std::vector<int> by_first(ns);
-            std::iota(by_first.begin(), by_first.end(), 0);
-            std::sort(by_first.begin(), by_first.end(), [&](int a, int b) { return F.sn[a].first < F.sn[b].first; });
-            for (int s : by_first) {
-                const int g = ctx->grp_owner[s], a = F.sn[s].first, e = a + F.sn[s].ncols;
-                for (int j = a; j < e; ++j) ctx->pipe_node_group[j] = g;
-                std::vector<std::pair<int, int> > &R = ctx->pipe_nodes[g < 0 ? ctx->pipe : g];
-                if (!R.empty() && R.back().second == a) R.back().second = e; else R.push_back({a, e});
-            }
-        }
-    }
     if (ctx->shard_mode != 1 || world <= 1) return;
     std::vector<double> load; int nt = 0; size_t nsub = 0;
     subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
@@ -187,27 +162,6 @@ void assign_elements(admm_hip_ctx *ctx) {
         } else {   // contiguous ranges (reference order preserved inside a rank)
             const int first = (int)((int64_t)b.n_total * ctx->rank / ctx->world), end = (int)((int64_t)b.n_total * (ctx->rank + 1) / ctx->world);
             for (int e = first; e < end; ++e) b.local.push_back(e);
-        }
-        b.grp_ptr.clear(); b.grp_blk.clear();
-        if (ctx->pipe > 1 && ctx->world == 1 && !ctx->grp_owner.empty()) {
-            // group-major: an element belongs to the group of its first node below the top (all its nodes below the top lie in ONE
-            // subtree); elements entirely inside the top are dealt round-robin.  Reference order is kept inside a group.
-            const int G = ctx->pipe;
-            std::vector<int> grp(b.local.size());
-            for (size_t el = 0; el < b.local.size(); ++el) {
-                int g = -1;
-                const int32_t *nd; const int nn = b.elem_nodes(b.local[el], &nd);
-                for (int c = 0; c < nn && g < 0; ++c) g = ctx->pipe_node_group[F.iperm[nd[c]]];
-                grp[el] = g < 0 ? (int)(b.local[el] % G) : g;
-            }
-            std::vector<int32_t> sorted; sorted.reserve(b.local.size());
-            b.grp_ptr.assign(G + 1, 0); b.grp_blk.assign(G + 1, 0);
-            for (int g = 0; g < G; ++g) {
-                for (size_t el = 0; el < b.local.size(); ++el) if (grp[el] == g) sorted.push_back(b.local[el]);
-                b.grp_ptr[g + 1] = (int)sorted.size();
-                b.grp_blk[g + 1] = b.grp_blk[g] + (b.grp_ptr[g + 1] - b.grp_ptr[g] + admm_dev::LOCAL_BLOCK - 1) / admm_dev::LOCAL_BLOCK;
-            }
-            b.local.swap(sorted);
         }
         b.n_local = (int)b.local.size();
         nloc += b.n_local;

@@ -367,38 +367,6 @@ def test_prereduced_rhs_and_unkept_z(pkg, monkeypatch):
     assert np.array_equal(c.read_local(0)["z"], d.read_local(0)["z"])
 
 
-@pytest.mark.parametrize("groups,scene", [("2", "bar"), ("3", "bar"), ("2", "mixed")])
-def test_pipelined_groups_bitwise_equal_serial_launch(pkg, monkeypatch, groups, scene):
-    """ADMM_HIP_PIPE=G (opt-in experiment): elements and elimination subtrees in G groups, every group's chain
-    bwd -> local step -> rhs -> fwd on its own stream, joined only at the top of the tree (System.cpp:51-67 is the loop being
-    re-ordered).  The pipelined frame (multi-stream, captured as graphs, or eager) must equal the SERIAL launch of the same
-    group-major layout bit for bit -- same kernels on the same data, only the interleaving differs -- and the default layout up
-    to the order of the per-node sums of the right-hand side."""
-    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
-
-    def make():
-        if scene == "bar":
-            s = pkg.make_bar_system(8, 8, 40, kind=KIND["TET_STVK"], device_id=0)
-        else:
-            s, _ = pkg.make_mixed_system(8, 8, 24, 24, 20)
-        s.initialize()
-        return s
-    ref = make()                                   # default layout
-    monkeypatch.setenv("ADMM_HIP_PIPE", groups)
-    piped = make()
-    serial = make(); serial.enable_timing(1)       # timing events around every phase: group after group on one stream
-    monkeypatch.setenv("ADMM_HIP_PIPE_GRAPH", "0")
-    eager = make()
-    for frame in range(3):
-        for s in (ref, piped, serial, eager):
-            s.step(6)
-        xp = piped.m_x
-        assert np.isfinite(xp).all()
-        assert np.array_equal(xp, serial.m_x), frame
-        assert np.array_equal(xp, eager.m_x), frame
-        assert np.abs(xp - ref.m_x).max() < 2e-5       # (the truncated prox amplifies the re-ordered sums within a frame, DESIGN 4.6)
-
-
 @pytest.mark.parametrize("dims,leaf", [((6, 5, 17), "16"), ((8, 8, 40), "0"), ((12, 12, 30), "64")])
 def test_device_factorization_vs_host(pkg, monkeypatch, dims, leaf):
     """The numeric multifrontal factorization on the GPU (csrc/factor_dev.hpp: MFMA fp64 products per 64-column block, block
@@ -756,12 +724,11 @@ def test_frame_graph_matches_per_iteration_graph(pkg, monkeypatch):
 
 def test_one_launch_local_step_matches_one_launch_per_batch(pkg, monkeypatch):
     """Scenes with several batches run their whole local step as ONE launch (project_multi_kernel: the batches' blocks back to back);
-    same per-element arithmetic, own outputs per element: bitwise equal to one launch per batch, and to the batches on side streams --
+    same per-element arithmetic, own outputs per element: bitwise equal to one launch per batch --
     the small mixed scene (NH + StVK tets, cloth triangles, hinges, anchors: five kinds), eager and graph-replayed."""
     out = []
-    for env in ({"ADMM_HIP_LOCAL_MULTI": "1"}, {"ADMM_HIP_LOCAL_MULTI": "0"}, {"ADMM_HIP_LOCAL_MULTI": "0", "ADMM_HIP_LOCAL_STREAMS": "4", "ADMM_HIP_LOCAL_STREAMS_MIN": "64"},
-                {"ADMM_HIP_LOCAL_MULTI": "1", "ADMM_HIP_GRAPH": "0"}):
-        for k in ("ADMM_HIP_LOCAL_MULTI", "ADMM_HIP_LOCAL_STREAMS", "ADMM_HIP_LOCAL_STREAMS_MIN", "ADMM_HIP_GRAPH"): monkeypatch.delenv(k, raising=False)
+    for env in ({"ADMM_HIP_LOCAL_MULTI": "1"}, {"ADMM_HIP_LOCAL_MULTI": "0"}, {"ADMM_HIP_LOCAL_MULTI": "1", "ADMM_HIP_GRAPH": "0"}, {"ADMM_HIP_LOCAL_MULTI": "0", "ADMM_HIP_GRAPH": "0"}):
+        for k in ("ADMM_HIP_LOCAL_MULTI", "ADMM_HIP_GRAPH"): monkeypatch.delenv(k, raising=False)
         for k, v in env.items(): monkeypatch.setenv(k, v)
         s, _ = pkg.make_mixed_system(4, 4, 12, 12, 12)
         s.initialize()

@@ -1,9 +1,9 @@
 #!/bin/bash
 # GPU box: the round's judged artefacts in one go -> gpurun_out/prof/{pmc_1M.json, bench_1M.json, bench_1M_under_rocprof.json,
-# bench_1M_kernel_stats.csv, level_trace_1M.txt, level_trace_fake8.txt, per_rank_kernel_time_fake_world.txt, bench_mixed.json};
+# bench_1M_kernel_stats.csv, level_trace_1M.txt, ranks_one_gpu.txt, ranks_one_gpu_rebalanced.txt, bench_mixed.json};
 # copy them into profiles/rNN/ afterwards.   usage: tools/profile_round.sh [rNN]
 cd $GRAFT_REPO_ROOT
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/prof
 mkdir -p $O
 export TMPDIR=/tmp
@@ -27,14 +27,8 @@ python tools/level_trace.py /tmp/prof_trace >> $O/level_trace_1M.txt 2>&1
 tail -12 $O/level_trace_1M.txt
 python bench.py --config mixed --no-extras > $O/bench_mixed.json 2>/dev/null
 tail -1 $O/bench_mixed.json | cut -c1-200
-# 5. what ONE rank of a 2 / 4 / 8-rank run computes per iteration (no-op all-reduce), and one rank's launches of an 8-rank run
-bash tools/fake_world.sh > $O/per_rank_kernel_time_fake_world.txt 2>&1
-for g in 0 1; do
-  BENCH_TIMING_EXPERIMENT=1 ADMM_HIP_GRAPH_COMM=$g ADMM_BENCH_FAKE_WORLD=8 ADMM_BENCH_FAKE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 \
-    bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>/dev/null | python3 tools/bench_summary.py "world8-subtree-rank0-rccl-in-library-graphcomm$g" >> $O/per_rank_kernel_time_fake_world.txt
-done
-cat $O/per_rank_kernel_time_fake_world.txt
-bash tools/fake_world_trace.sh 8 > /dev/null 2>&1; cp gpurun_out/level_trace_fake8.txt $O/level_trace_fake8.txt
-# 6. what each RANK's local step costs with real physics: the tet kernel launched once per subtree group of the rank partition
-for G in 2 4 8; do bash tools/group_local_times.sh $G; done > $O/group_local_times.txt 2>&1
-cat $O/group_local_times.txt
+# 5. what every RANK of a 2 / 4 / 8-rank run computes per iteration, real physics, one rank on the GPU at a time (tools/ranks_one_gpu.py),
+#    plus the rebalanced partition (cost-weighted top separators after the second warm-up frame)
+for w in 2 4 8; do timeout 300 python tools/ranks_one_gpu.py --world $w --warm 2 --frames 1 2>&1 | grep -v amdgpu.ids; done > $O/ranks_one_gpu.txt
+for w in 2 4 8; do timeout 300 python tools/ranks_one_gpu.py --world $w --warm 2 --frames 1 --rebalance -2 2>&1 | grep -v amdgpu.ids; done > $O/ranks_one_gpu_rebalanced.txt
+cat $O/ranks_one_gpu.txt $O/ranks_one_gpu_rebalanced.txt
