@@ -94,7 +94,9 @@ struct ND {
             for (int v : nodes) tot += wnode[v];
             int i = 0;
             for (; i < m; ++i) { acc += wnode[nodes[i]]; if (acc >= 0.5 * tot) break; }
-            half = std::min(std::max(i + 1, 1), m - 1);
+            // node i straddles the half: it goes left only if that leaves the two sides closer (ties: right, which is what m / 2 does for uniform weights)
+            const bool left = i < m && (acc - 0.5 * tot) < (0.5 * tot - (acc - wnode[nodes[i]]));
+            half = std::min(std::max(left ? i + 1 : i, 1), m - 1);
         } else std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), cmp);
         const int tl = next_tag++, tr = next_tag++;
         for (int i = 0; i < half; ++i) tag[nodes[i]] = tl;

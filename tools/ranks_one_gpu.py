@@ -90,13 +90,17 @@ def main():
     p.add_argument("--warm", type=int, default=1)
     p.add_argument("--iters", type=int, default=20)
     p.add_argument("--rebalance", type=int, default=None, help="call rebalance() on every rank after this timed frame (0-based; negative: counted back from the end of the warm-up, -1 = after the last warm-up frame)")
+    p.add_argument("--config", choices=["bar", "mixed"], default="bar", help="mixed: BASELINE configs[4] (26x26x123 NH + StVK bar, 158x158 cloth)")
     p.add_argument("--json", action="store_true")
     a = p.parse_args()
     import torch
     from __graft_entry__ import load_package
     pkg = load_package()
     W = a.world
-    shards = [pkg.make_bar_system(*a.dims, rank=r, world=W, shard_mode=a.mode) for r in range(W)]
+    if a.config == "mixed":
+        shards = [pkg.make_mixed_system(26, 26, 123, 158, 158, rank=r, world=W, shard_mode=a.mode)[0] for r in range(W)]
+    else:
+        shards = [pkg.make_bar_system(*a.dims, rank=r, world=W, shard_mode=a.mode) for r in range(W)]
     bat = Baton(W, torch)
     for r, s in enumerate(shards):
         s.set_allreduce(bat.hook(r)); s.keep_z(False)
@@ -150,7 +154,7 @@ def main():
         print(json.dumps(out))
         return
     print("ranks on one GPU: world %d, %s shards, bar %s, %d warm-up + %d timed frames of %d iterations%s" % (
-        W, a.mode, "x".join(map(str, a.dims)), a.warm, a.frames, a.iters, ("; rebalance after frame %d (negative: warm-up)" % a.rebalance) if a.rebalance is not None else ""))
+        W, a.mode, "x".join(map(str, a.dims)) if a.config == "bar" else "(mixed scene of configs[4])", a.warm, a.frames, a.iters, ("; rebalance after frame %d (negative: warm-up)" % a.rebalance) if a.rebalance is not None else ""))
     print("elements per rank %s; nodes own %s + top %d; exchange %d bytes per iteration; all ranks bitwise equal: %s" % (
         out["elements"], out["nodes_own"], out["nodes_top"], out["comm_bytes_per_iter"], same))
     for f, row in enumerate(out["per_frame"]):
