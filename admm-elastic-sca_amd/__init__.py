@@ -107,8 +107,6 @@ def lib():
         L.admm_hip_finalize.argtypes = [C.c_void_p]
         L.admm_hip_set_weights.argtypes = [C.c_void_p, C.c_int, _dp]
         L.admm_hip_recompute_weights.argtypes = [C.c_void_p]
-        L.admm_hip_rebalance.argtypes = [C.c_void_p]
-        L.admm_hip_debug_set_node_weights.argtypes = [C.c_void_p, _dp, C.c_int]
         L.admm_hip_update_anchors.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
         L.admm_hip_step.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_sync.argtypes = [C.c_void_p]
@@ -335,14 +333,6 @@ class System:
 
     def recompute_weights(self):
         self._chk(self.L.admm_hip_recompute_weights(self.h))
-
-    def rebalance(self):
-        """admm_hip_rebalance: the partition re-drawn from the measured element costs (collective: every rank at the same frame)"""
-        self._chk(self.L.admm_hip_rebalance(self.h))
-
-    def set_node_weights(self, w, levels):
-        w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
-        self._chk(self.L.admm_hip_debug_set_node_weights(self.h, _d(w), int(levels)))
 
     def set_weights(self, batch, w):
         w = np.ascontiguousarray(w, dtype=np.float64)

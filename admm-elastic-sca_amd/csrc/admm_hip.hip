@@ -65,7 +65,6 @@ extern "C" {
 
 #include "abi_setup.inc"
 #include "abi_step.inc"
-#include "rebalance.inc"
 #include "abi_parity.inc"
 
 } // extern "C"

@@ -136,9 +136,6 @@ struct admm_hip_ctx {
     // elimination tree and the elements that touch them; only the top of the tree is replicated
     int shard_mode = 0;                       // 0: contiguous element ranges + replicated solve, 1: subtrees
     std::vector<int> sn_owner, node_owner;    // -1 = top (replicated); node_owner in factor order
-    // admm_hip_rebalance: per node (original ids) what it weighs when the top `weighted_depth` bisections of the nested dissection are cut
-    // (empty: count medians); x_rest: the positions the dissection's geometry is taken from (those of admm_hip_finalize, whatever m_x is now)
-    std::vector<double> node_weight, x_rest; int weighted_depth = 0;
     std::vector<LevelDev> levels_top;         // sweep items of the top supernodes (levels = this rank's own ones)
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;
@@ -250,7 +247,7 @@ void partition_subtrees(admm_hip_ctx *ctx);                                     
 void assign_elements(admm_hip_ctx *ctx);
 void top_needs(const admm_hip_ctx *ctx, std::vector<std::vector<char> > &need, std::vector<int> &provider);
 void shard_accounting(admm_hip_ctx *ctx);
-void subtree_owners(const admm_host::Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub, const double *node_weight = nullptr);
+void subtree_owners(const admm_host::Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub);
 void xcd_order(std::vector<admm_dev::SweepItem> &items, int group, int min_supernodes);
 
 } // namespace admm_lib

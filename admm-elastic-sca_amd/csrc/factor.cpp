@@ -65,7 +65,6 @@ namespace {
 struct ND {
     const std::vector<int64_t> *adjp; const std::vector<int> *adj; const double *xyz;
     int leaf;
-    const double *wnode = nullptr; int wdepth = 0;      // weighted medians for the bisections above depth `wdepth` (analyze)
     std::vector<int> tag;     // scratch region tag per node
     int next_tag = 1;
     std::vector<int> order;   // new -> old
@@ -80,24 +79,15 @@ struct ND {
 
     // One bisection: median split of `nodes` along their longest axis; the smaller of the two boundary sets becomes the
     // separator.  L, R: the two sides without the separator; sep sorted along the axis.
-    void bisect(std::vector<int> &nodes, std::vector<int> &L, std::vector<int> &R, std::vector<int> &sepc, int depth = 1 << 30) {
+    void bisect(std::vector<int> &nodes, std::vector<int> &L, std::vector<int> &R, std::vector<int> &sepc) {
         const int m = (int)nodes.size();
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int v : nodes) for (int c = 0; c < 3; ++c) { double q = xyz[3 * (size_t)v + c]; lo[c] = std::min(lo[c], q); hi[c] = std::max(hi[c], q); }
         int ax = 0; double ext = hi[0] - lo[0];
         for (int c = 1; c < 3; ++c) if (hi[c] - lo[c] > ext) { ext = hi[c] - lo[c]; ax = c; }
-        int half = m / 2;
+        const int half = m / 2;
         auto cmp = [&](int a, int b) { double qa = xyz[3 * (size_t)a + ax], qb = xyz[3 * (size_t)b + ax]; return qa < qb || (qa == qb && a < b); };
-        if (wnode && depth < wdepth && m >= 4) {      // weighted median: the first position where the left side holds half of the region's weight
-            std::sort(nodes.begin(), nodes.end(), cmp);
-            double tot = 0.0, acc = 0.0;
-            for (int v : nodes) tot += wnode[v];
-            int i = 0;
-            for (; i < m; ++i) { acc += wnode[nodes[i]]; if (acc >= 0.5 * tot) break; }
-            // node i straddles the half: it goes left only if that leaves the two sides closer (ties: right, which is what m / 2 does for uniform weights)
-            const bool left = i < m && (acc - 0.5 * tot) < (0.5 * tot - (acc - wnode[nodes[i]]));
-            half = std::min(std::max(left ? i + 1 : i, 1), m - 1);
-        } else std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), cmp);
+        std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), cmp);
         const int tl = next_tag++, tr = next_tag++;
         for (int i = 0; i < half; ++i) tag[nodes[i]] = tl;
         for (int i = half; i < m; ++i) tag[nodes[i]] = tr;
@@ -137,7 +127,7 @@ struct ND {
         if (H.empty()) return;
         if ((int)H.size() <= leaf || d == 0) { kids.push_back(rec(H, depth)); return; }
         std::vector<int> a, b, sh;
-        bisect(H, a, b, sh, depth);
+        bisect(H, a, b, sh);
         gather(a, d - 1, depth + 1, kids, cols);
         gather(b, d - 1, depth + 1, kids, cols);
         cols.insert(cols.end(), sh.begin(), sh.end());
@@ -147,7 +137,7 @@ struct ND {
         if (m <= leaf) return emit(nodes);
         bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small) || (root_depth > 1 && depth == 0);
         std::vector<int> L, R, sep;
-        bisect(nodes, L, R, sep, depth);
+        bisect(nodes, L, R, sep);
         // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
         if (four && merge_root && depth == 0 && !(merge > 0 && m > merge) && 3 * sep.size() > 4096) four = false;
         std::vector<int> kids;
@@ -170,8 +160,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth,
-            const double *node_weight, int weighted_depth) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -186,7 +175,6 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
     ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth;
-    nd.wnode = node_weight; nd.wdepth = weighted_depth;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);

@@ -68,10 +68,7 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 // merge_small > 0: regions of at most that many nodes (above the leaf size) become four-way nodes too (fewer, fatter levels near the leaves)
 // merge_depth: bisection levels a merged node spans (2: four-way nodes, 3: eight-way nodes with seven separators in one supernode);
 // root_depth > 1: the same for the root node alone
-// node_weight / weighted_depth (admm_hip_rebalance): the bisections of the top `weighted_depth` levels cut at the WEIGHTED median of their
-// nodes along the split axis instead of the count median (both sides carry the same weight, not the same number of nodes)
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0,
-            const double *node_weight = nullptr, int weighted_depth = 0);
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0);
 
 // Layout of Factor::panels from the symbolic structure alone: Supernode::root_inv_off and Factor::panels_size.
 void plan_panels(Factor &F);

@@ -130,7 +130,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
     if (const char *e = getenv("ADMM_HIP_THREADS")) if (atoi(e) > 0) threads = atoi(e);
     ctx->info.host_threads = threads;
     if (!reuse_symbolic) {
-        std::vector<double> xyz(ctx->x_rest.size() == ctx->x.size() ? ctx->x_rest : ctx->x);      // the geometry of admm_hip_finalize (a re-ordering in mid-run must not follow the deformation)
+        std::vector<double> xyz(ctx->x);
         // Larger dissection leaves = fewer elimination-tree levels (each costs >= 7-10 us per sweep whatever its size) for a little
         // more fill.  Measured (tools/leaf_sweep.py, us per ADMM iteration, leaf 16 / 64 / 128 / 256): 18.8k nodes 266 / 251 / 235 / 229,
         // 44k nodes 334 / 318 / 321 / 322, 178.6k nodes 982 / 954 / 1026 / 1020.
@@ -169,7 +169,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         if (const char *e = getenv("ADMM_HIP_MERGE_DEPTH")) merge_depth = atoi(e);
         int root_depth = 0;
         if (const char *e = getenv("ADMM_HIP_ROOT_DEPTH")) root_depth = atoi(e);
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth, ctx->node_weight.empty() ? nullptr : ctx->node_weight.data(), ctx->weighted_depth);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth);
         // Tree search (systems between the dense limit and 160k nodes on one GPU, no ordering knob set by hand): the thresholds above were
         // measured on bars; other shapes get the same trade-off from a cost model of the two sweeps fitted to 192 measured (scene, tree) pairs
         // (tools/probe/tree_model_data.py, NOTES section E): 11.9 us per level below the roots (both sweeps: launch + dependent chain), 0.48 us per MB

@@ -11,16 +11,13 @@ namespace admm_lib {
 // rank, then give the subtrees to the ranks largest first (LPT).  Every vertex separator is a supernode, so an element
 // whose nodes are not all in the top lies inside exactly ONE subtree plus its ancestors: it goes to that subtree's rank.
 // `owner` <- part of every supernode (-1 = top) for `parts` parts; returns the loads through `load`, counts through n_top / n_sub
-// node_weight (admm_hip_rebalance; per ORIGINAL node id): a subtree weighs the sum of its nodes' weights instead of its factor entries --
-// the quantity the weighted bisections equalised, so the splitting stops at one subtree per rank instead of chasing the entries' imbalance
-void subtree_owners(const Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub, const double *node_weight) {
+void subtree_owners(const Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub) {
     const int ns = (int)F.sn.size(), world = parts;
     owner.assign(ns, 0);
     std::vector<double> weight(ns, 0.0);
     std::vector<std::vector<int> > kids(ns);
     for (int s = 0; s < ns; ++s) {   // postorder: children come before parents
-        if (node_weight) for (int j = 0; j < F.sn[s].ncols; ++j) weight[s] += node_weight[F.perm[F.sn[s].first + j]];
-        else weight[s] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
+        weight[s] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
         if (F.sn[s].parent >= 0) { weight[F.sn[s].parent] += weight[s]; kids[F.sn[s].parent].push_back(s); }
     }
     std::vector<char> top(ns, 0);
@@ -72,11 +69,11 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
     if (ctx->shard_mode != 1 || world <= 1) return;
     std::vector<double> load; int nt = 0; size_t nsub = 0;
-    subtree_owners(F, world, ctx->sn_owner, load, nt, nsub, ctx->node_weight.empty() ? nullptr : ctx->node_weight.data());
+    subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
     for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];
     if (getenv("ADMM_HIP_VERBOSE")) {
-        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (%s):", nt, nsub, ctx->node_weight.empty() ? "1e6 entries" : "1e3 node weights");
-        for (double l : load) fprintf(stderr, " %.1f", l * (ctx->node_weight.empty() ? 1e-6 : 1e-3));
+        fprintf(stderr, "admm_hip: subtree sharding: %d top supernodes, %zu subtrees, load per rank (1e6 entries):", nt, nsub);
+        for (double l : load) fprintf(stderr, " %.1f", l * 1e-6);
         fprintf(stderr, "\n");
     }
 }

@@ -155,17 +155,6 @@ int admm_hip_rccl_async_error(admm_hip_ctx *ctx, int *nccl_result);
  * it for what the reference keeps per force object and a sharded run keeps on the owner rank only: a released MovingAnchor's
  * position, point->pos = Dx of the last project() (AnchorForce.cpp:80-83) -- owner's value, zeros elsewhere.              */
 int admm_hip_allreduce_host(admm_hip_ctx *ctx, double *host_buf, int64_t count);
-/* Re-draws the partition from what the elements really cost (any time after a step; every rank must call it at the same point of
- * the simulation -- it contains one collective through the installed transport).  The tet kernels record the real time of every
- * 64-tet block of a frame; rebalance turns the records of all ranks into node weights (share ADMM_HIP_COST_MIX of measured cost, the
- * rest node count), cuts the top bisections of the nested dissection -- the ones that separate the ranks' subtrees -- at the weighted
- * median, factors the re-ordered system (0.3-0.6 s at 1M tets) and carries x, v, every element's u and warm start over to its new
- * owner.  The iterates continue up to the order of the fp64 sums (DESIGN 4.6 envelope), bitwise identical on all ranks.  Small
- * (explicit-inverse) systems: no-op.  Not with user-defined forces.  No reference counterpart (single process).                     */
-int admm_hip_rebalance(admm_hip_ctx *ctx);
-/* (tests: the weights admm_hip_rebalance would derive, handed in directly before finalize -- per node, original ids; `levels`
- *  top bisections use them.  NULL / 0 clears.)                                                                                 */
-int admm_hip_debug_set_node_weights(admm_hip_ctx *ctx, const double *w, int levels);
 /* How the work is split across the ranks (before finalize; env ADMM_HIP_SHARD=contiguous|subtree overrides):
  *   ADMM_SHARD_CONTIGUOUS  every batch is cut into `world` contiguous element ranges; per ADMM iteration the whole right-hand
  *                          side (3 n doubles) is all-reduced and every rank runs the complete solve.

@@ -169,40 +169,6 @@ def test_subtree_partition_unstructured(pkg, monkeypatch, world):
     assert loads.max() < 1.6 * loads.mean()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_weighted_top_separators_balance_weight_not_count(pkg, monkeypatch, world):
-    """admm_hip_rebalance's ordering, host side: with node weights the top bisections cut at the WEIGHTED median -- every rank's
-    subtree carries the same weight (here: the far third of the bar weighs four times the rest, like the bending end of the 1M bar
-    costs more per tet) and fewer nodes where they are heavy; the partition stays a partition and every rank draws the same one."""
-    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
-    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
-    dims = (6, 6, 60)
-    x, t = pkg.meshgen.bar(*dims)
-    w = np.where(x[:, 2] > 2.0, 4.0, 1.0)                     # z runs to 3.0
-    res = {}
-    for weighted in (False, True):
-        systems = []
-        for r in range(world):
-            s = pkg.make_bar_system(*dims, device_id=-1, rank=r, world=world, shard_mode="subtree")
-            if weighted:
-                s.set_node_weights(w, 2)
-            s.initialize(); systems.append(s)
-        owner = systems[0].node_owner()
-        assert all(np.array_equal(s.node_owner(), owner) for s in systems[1:])
-        seen = np.zeros(t.shape[0], np.int32)
-        for s in systems:
-            seen[s.local_elements(0)] += 1
-        assert np.all(seen == 1)
-        res[weighted] = (np.array([(owner == r).sum() for r in range(world)], float), np.array([w[owner == r].sum() for r in range(world)]), (owner == -1).sum())
-    cnt0, wt0, top0 = res[False]; cnt1, wt1, top1 = res[True]
-    assert cnt0.max() / cnt0.min() < 1.15 and wt0.max() / wt0.min() > 1.5          # count medians: equal counts, unequal weight
-    assert wt1.max() / wt1.min() < 1.3 and cnt1.max() / cnt1.min() > 1.5           # weighted medians: equal weight (up to the separators, 49 nodes each here), unequal counts
-    assert top1 <= 1.3 * top0                                                       # ... without a larger replicated top
-    b = np.random.default_rng(1).normal(size=3 * x.shape[0])                        # the re-ordered factor still solves the system
-    xs = systems[0].debug_panel_solve_host(b)
-    assert np.abs(systems[0].apply_A(xs) - b).max() < 1e-10 * np.abs(b).max()
-
-
 def _thread_allreduce_hooks(world):
     """all-reduce between `world` contexts living in ONE process on ONE GPU (threads meeting at barriers)"""
     import torch
@@ -321,126 +287,6 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
             for f in range(3):
                 assert np.abs(xs[f] - refx[f]).max() < tol, (name, r, f, np.abs(xs[f] - refx[f]).max())
             assert np.array_equal(xs[-1], out[0][1][-1]) and np.array_equal(vs, out[0][2])      # all ranks end bitwise identical
-
-
-def _run_with_rebalance(shards, frames_before, frames_after, iters, rebalance=True):
-    """every rank on its own thread: frames, admm_hip_rebalance (collective), frames -> per rank (x after every frame, v, elements owned)"""
-    world = len(shards)
-    out = [None] * world
-    errs = []
-
-    def run(r):
-        try:
-            s = shards[r]; xs = []
-            for _ in range(frames_before):
-                s.step(iters); xs.append(s.m_x.copy())
-            if rebalance:
-                s.rebalance()
-            for _ in range(frames_after):
-                s.step(iters); xs.append(s.m_x.copy())
-            out[r] = (xs, s.m_v.copy(), [s.local_elements(b).copy() for b in range(len(s.batches))])
-        except Exception as e:  # noqa: BLE001
-            errs.append((r, repr(e)))
-            raise
-    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    [t_.start() for t_ in th]
-    [t_.join(timeout=600) for t_ in th]
-    assert not errs, errs
-    return out
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_rebalance_carries_the_state_over_bitwise_when_the_partition_stays(pkg, monkeypatch, world):
-    """admm_hip_rebalance on a scene whose kinds record no cost (corotational tets on an unstructured mesh + anchors, a cloth): the
-    weights stay uniform, the ordering and the partition come out the same -- so everything that differs from a run without
-    rebalance would be lost state.  x, v, u of every element survive the trip through the full-size exchange arrays: the frames after
-    the rebalance are BITWISE those of the run that never rebalanced, on every rank."""
-    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
-    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
-    from scipy.spatial import Delaunay
-    from conftest import golden
-    prng = np.random.default_rng(7)
-    pts = prng.uniform(0, 1, size=(900, 3)) * np.array([1.0, 1.0, 3.0])
-    tets = Delaunay(pts).simplices.astype(np.int32)
-    vol = np.abs(np.einsum("ij,ij->i", pts[tets[:, 1]] - pts[tets[:, 0]], np.cross(pts[tets[:, 2]] - pts[tets[:, 0]], pts[tets[:, 3]] - pts[tets[:, 0]]))) / 6.0
-    tets = tets[vol > 1e-3 * vol.mean()]
-    g = golden("traj_cloth.npz")
-
-    def delaunay(rank, w):
-        s = pkg.System(device_id=0); s.set_timestep(0.02)
-        s.add_nodes(pts.ravel(), np.full(3 * pts.shape[0], 1.0 / pts.shape[0]))
-        s.add_forces(pkg.KIND["TET_LINEAR"], tets, [50.0])
-        s.add_forces(pkg.KIND["ANCHOR"], np.nonzero(pts[:, 2] < 0.2)[0].astype(np.int32), [-1.0, 1.0])
-        s.add_gravity([0, -9.8, 0])
-        if w > 1:
-            s.set_shard(rank, w); s.set_shard_mode("subtree")
-        return s
-
-    def cloth(rank, w):
-        n = g["x"].shape[0]
-        s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
-        s.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
-        s.add_forces(pkg.KIND["TRI_STRAIN"], g["tris"], [float(g["k_tri"]), g["lim"][0], g["lim"][1], 1.0])
-        s.add_forces(pkg.KIND["BEND"], g["hinges"], [float(g["k_bend"])])
-        s.add_forces(pkg.KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
-        s.add_gravity([0, -9.8, 0])
-        if w > 1:
-            s.set_shard(rank, w); s.set_shard_mode("subtree")
-        return s
-    for name, make in (("delaunay", delaunay), ("cloth", cloth)):
-        res = {}
-        for reb in (False, True):
-            shards = [make(r, world) for r in range(world)]
-            hooks = _thread_allreduce_hooks(world)
-            for r, s in enumerate(shards):
-                if world > 1:
-                    s.set_allreduce(hooks[r])
-                s.initialize()
-            res[reb] = _run_with_rebalance(shards, 2, 3, 10, rebalance=reb)
-        for r in range(world):
-            for b in range(len(res[True][r][2])):
-                assert np.array_equal(res[True][r][2][b], res[False][r][2][b]), (name, r, b, "the partition moved without a cost record")
-            for f in range(5):
-                assert np.array_equal(res[True][r][0][f], res[False][r][0][f]), (name, r, f, np.abs(res[True][r][0][f] - res[False][r][0][f]).max())
-            assert np.array_equal(res[True][r][1], res[False][r][1])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,kind", [(2, "TET_NH"), (4, "TET_STVK"), (8, "TET_NH")])
-def test_rebalance_moves_elements_and_continues_the_trajectory(pkg, monkeypatch, world, kind):
-    """admm_hip_rebalance on hyperelastic bars (the kinds that record their cost): the top separators move to where the measured
-    cost balances, elements change owners -- the partition stays exact (every element on one rank), all ranks stay BITWISE identical,
-    u and the warm start arrive with their elements (the frame after the rebalance is within the truncated minimiser's envelope of
-    the run that never rebalanced: lost state would show as a jump of the size of the deformation), the simulation goes on."""
-    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
-    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
-    monkeypatch.setenv("ADMM_HIP_COST_MIX", "1.0")        # all weight on the measured cost: the partition must move
-    dims = (6, 6, 80)
-    n_tets = 6 * 6 * 80 * 6
-    res = {}
-    for reb in (False, True):
-        shards = [pkg.make_bar_system(*dims, kind=pkg.KIND[kind], rank=r, world=world, shard_mode="subtree") for r in range(world)]
-        hooks = _thread_allreduce_hooks(world)
-        for r, s in enumerate(shards):
-            s.set_allreduce(hooks[r]); s.initialize()
-        res[reb] = _run_with_rebalance(shards, 3, 3, 10, rebalance=reb)
-    out, plain = res[True], res[False]
-    seen = np.zeros(n_tets, np.int32)
-    for r in range(world):
-        seen[out[r][2][0]] += 1
-        for f in range(6):
-            assert np.array_equal(out[r][0][f], out[0][0][f]), (r, f)      # every rank, every frame: the same bits
-        assert np.array_equal(out[r][1], out[0][1])
-    assert np.all(seen == 1)
-    moved = sum(not np.array_equal(out[r][2][0], plain[r][2][0]) for r in range(world))
-    assert moved >= 2, "the measured cost did not move the partition"
-    for f in range(3):
-        assert np.array_equal(out[0][0][f], plain[0][0][f])               # before the rebalance: the same run
-    disp = np.abs(plain[0][0][3] - plain[0][0][2]).max()                    # how far a frame moves the bar
-    d3 = np.abs(out[0][0][3] - plain[0][0][3]).max()
-    assert np.isfinite(out[0][0][5]).all() and d3 < 2e-5 and d3 < 1e-2 * disp, (d3, disp)
-    assert np.abs(out[0][0][5] - plain[0][0][5]).max() < 1e-3 * max(disp, 1e-3)
 
 
 @pytest.mark.gpu

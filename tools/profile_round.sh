@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the round's judged artefacts in one go -> gpurun_out/prof/{pmc_1M.json, bench_1M.json, bench_1M_under_rocprof.json,
-# bench_1M_kernel_stats.csv, level_trace_1M.txt, ranks_one_gpu.txt, ranks_one_gpu_rebalanced.txt, bench_mixed.json};
+# bench_1M_kernel_stats.csv, level_trace_1M.txt, ranks_one_gpu.txt, ranks_one_gpu_contiguous.txt, bench_mixed.json};
 # copy them into profiles/rNN/ afterwards.   usage: tools/profile_round.sh [rNN]
 cd $GRAFT_REPO_ROOT
 R=${1:-r05}
@@ -27,8 +27,7 @@ python tools/level_trace.py /tmp/prof_trace >> $O/level_trace_1M.txt 2>&1
 tail -12 $O/level_trace_1M.txt
 python bench.py --config mixed --no-extras > $O/bench_mixed.json 2>/dev/null
 tail -1 $O/bench_mixed.json | cut -c1-200
-# 5. what every RANK of a 2 / 4 / 8-rank run computes per iteration, real physics, one rank on the GPU at a time (tools/ranks_one_gpu.py),
-#    plus the rebalanced partition (cost-weighted top separators after the second warm-up frame)
+# 5. what every RANK of a 2 / 4 / 8-rank run computes per iteration, real physics, one rank on the GPU at a time (tools/ranks_one_gpu.py)
 for w in 2 4 8; do timeout 300 python tools/ranks_one_gpu.py --world $w --warm 2 --frames 1 2>&1 | grep -v amdgpu.ids; done > $O/ranks_one_gpu.txt
-for w in 2 4 8; do timeout 300 python tools/ranks_one_gpu.py --world $w --warm 2 --frames 1 --rebalance -2 2>&1 | grep -v amdgpu.ids; done > $O/ranks_one_gpu_rebalanced.txt
-cat $O/ranks_one_gpu.txt $O/ranks_one_gpu_rebalanced.txt
+for w in 2 4 8; do timeout 300 python tools/ranks_one_gpu.py --world $w --warm 2 --frames 1 --mode contiguous 2>&1 | grep -v amdgpu.ids; done > $O/ranks_one_gpu_contiguous.txt
+cat $O/ranks_one_gpu.txt $O/ranks_one_gpu_contiguous.txt

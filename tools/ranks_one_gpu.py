@@ -11,8 +11,7 @@ is NOT measured: the collective itself (xGMI) -- the hook's wait shows up in all
 Replaces the round-2..4 methodology (a fake world with a no-op all-reduce for the sweeps + ADMM_HIP_PIPE groups for the
 local step): one run, right physics, no extra code path in the library.
 
-  python tools/ranks_one_gpu.py --world 4 [--mode subtree|contiguous] [--dims 32 32 163] [--frames 3] [--warm 1]
-                                [--rebalance F]   call admm_hip_rebalance after frame F (cost-weighted top separators)
+  python tools/ranks_one_gpu.py --world 4 [--mode subtree|contiguous] [--dims 32 32 163 | --config mixed] [--frames 3] [--warm 1]
 """
 import argparse
 import json
@@ -89,7 +88,6 @@ def main():
     p.add_argument("--frames", type=int, default=3)
     p.add_argument("--warm", type=int, default=1)
     p.add_argument("--iters", type=int, default=20)
-    p.add_argument("--rebalance", type=int, default=None, help="call rebalance() on every rank after this timed frame (0-based; negative: counted back from the end of the warm-up, -1 = after the last warm-up frame)")
     p.add_argument("--config", choices=["bar", "mixed"], default="bar", help="mixed: BASELINE configs[4] (26x26x123 NH + StVK bar, 158x158 cloth)")
     p.add_argument("--json", action="store_true")
     a = p.parse_args()
@@ -116,16 +114,12 @@ def main():
             s = shards[r]
             for f in range(a.warm):
                 s.step(a.iters)
-                if a.rebalance is not None and a.rebalance == f - a.warm:      # (negative: during the warm-up)
-                    s.rebalance()
             s.enable_timing(1)
             for f in range(a.frames):
                 s.step(a.iters)
                 t = s.timing()
                 for k in keys:
                     acc[r][f][k] = t[k] / a.iters
-                if a.rebalance is not None and a.rebalance == f:
-                    s.enable_timing(0); s.rebalance(); s.enable_timing(1)
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
             with bat.cv:
@@ -140,7 +134,7 @@ def main():
     xs = [s.m_x for s in shards]
     same = all(np.array_equal(xs[0], x) for x in xs[1:])
     infos = [s.info() for s in shards]
-    out = {"world": W, "mode": a.mode, "dims": a.dims, "frames": a.frames, "warm": a.warm, "iters": a.iters, "rebalance_after_frame": a.rebalance,
+    out = {"world": W, "mode": a.mode, "dims": a.dims, "frames": a.frames, "warm": a.warm, "iters": a.iters, 
            "all_ranks_bitwise_equal": bool(same), "finite": bool(np.isfinite(xs[0]).all()), "x_checksum": float(np.abs(xs[0]).sum()),
            "per_frame": [], "elements": [int(i["n_elems_local"]) for i in infos], "nodes_own": [int(i["nodes_own"]) for i in infos], "nodes_top": int(infos[0]["nodes_top"]),
            "comm_bytes_per_iter": 8 * int(infos[0]["comm_doubles_iter"])}
@@ -154,7 +148,7 @@ def main():
         print(json.dumps(out))
         return
     print("ranks on one GPU: world %d, %s shards, bar %s, %d warm-up + %d timed frames of %d iterations%s" % (
-        W, a.mode, "x".join(map(str, a.dims)) if a.config == "bar" else "(mixed scene of configs[4])", a.warm, a.frames, a.iters, ("; rebalance after frame %d (negative: warm-up)" % a.rebalance) if a.rebalance is not None else ""))
+        W, a.mode, "x".join(map(str, a.dims)) if a.config == "bar" else "(mixed scene of configs[4])", a.warm, a.frames, a.iters, ""))
     print("elements per rank %s; nodes own %s + top %d; exchange %d bytes per iteration; all ranks bitwise equal: %s" % (
         out["elements"], out["nodes_own"], out["nodes_top"], out["comm_bytes_per_iter"], same))
     for f, row in enumerate(out["per_frame"]):
