@@ -15,10 +15,11 @@
 // Everything the solver reads is reproduced bit for bit: vertices are `float`, the
 // transform is applied in double and rounded back to float per coordinate, and the
 // same libstdc++ stream conversions parse and print the numbers.  What is NOT here:
-// rendering data (normals, tstrips, textures, materials, lights, cameras, BVH) and
-// mclscene's tessellators for sphere/box/beam/cylinder/torus and its ply/obj readers.
-// Such objects are accepted as static scenery (their parameters are kept, which is
-// all the samples read from them); giving one a <Force> is an error.
+// rendering data (normals, tstrips, textures, materials, lights, cameras, BVH), trimesh2's
+// ply/obj readers ("trimesh" objects from files) and point clouds: such objects are accepted
+// as static scenery (their parameters are kept); giving one a <Force> is an error.
+//   sphere / box / beam / cylinder / torus       (mclscene DefaultBuilders.hpp:83-256 over trimesh2 TriMeshBuilder.h:220-556,
+//                                                 libsrc/remove.cc) -- round 5: tessellated like the reference does, forces attach
 //
 // Bit parity with the reference needs the arithmetic below compiled without FMA
 // contraction (-ffp-contract=off, the default x86-64 baseline has no FMA anyway).
@@ -205,6 +206,200 @@ static inline void make_sym_plane(TriMesh *mesh, int tess_x, int tess_y) {
             mesh->faces.push_back(TriMesh::Face(cent, ur, ul));
             mesh->faces.push_back(TriMesh::Face(ll, cent, ul));
         }
+}
+
+
+// ---- mclscene's primitive objects (DefaultBuilders.hpp:83-256 call these): sphere, box / cube, beam, cylinder, torus --------------
+// Restated from trimesh2's TriMeshBuilder.h (make_cube :220-340, make_sphere_polar :343-382, make_beam :385-422, make_ccyl :426-494,
+// make_cyl :497-522, make_torus :525-556) and libsrc/remove.cc (remove_faces, remove_unused_vertices): the vertex ORDER and every float
+// operation matter -- ForceBuilder numbers the solver's nodes by vertex index and lumps masses from these coordinates -- so the loops
+// keep trimesh2's order and its arithmetic: angles are `constant_f * int / int` in float; the unqualified cos / sin of TriMeshBuilder.h
+// resolve to the C library's DOUBLE functions (no `using namespace std` at that scope), so a float angle is promoted, `r * cos(ph)` is a
+// double product, and the value is rounded to float only when it becomes a vertex coordinate -- except the torus tube, which calls cosf /
+// sinf by name.  Settled against fixtures dumped from the reference's own loader (tests/golden/scene_shapes.npz): the float overloads differ
+// from this in the last bit on 29 of 1227 coordinates of that scene.
+namespace detail {
+static const float kPif = 3.1415927f, kTwoPif = 6.2831855f;      // TriMesh.h:16-17 M_PIf, Color.h:25-26 M_TWOPIf
+inline void quad(TriMesh *m, int ll, int lr, int ul, int ur) { m->faces.push_back(TriMesh::Face(ll, lr, ur)); m->faces.push_back(TriMesh::Face(ll, ur, ul)); }
+inline int sq(int v) { return v * v; }
+inline double dcos(float a) { return ::cos((double)a); }
+inline double dsin(float a) { return ::sin((double)a); }
+} // namespace detail
+
+static inline void make_sphere_polar(TriMesh *mesh, int tess_ph, int tess_th) {
+    using namespace detail;
+    tess_th = std::max(tess_th, 3); tess_ph = std::max(tess_ph, 3);
+    mesh->vertices.push_back(point(0, 0, -1));
+    for (int j = 1; j < tess_th; ++j) {                       // rings from the south pole up
+        const float th = kPif * j / tess_th;
+        const float z = (float)-dcos(th), r = (float)dsin(th);
+        for (int i = 0; i < tess_ph; ++i) { const float ph = kTwoPif * i / tess_ph; mesh->vertices.push_back(point((float)(r * dcos(ph)), (float)(r * dsin(ph)), z)); }
+    }
+    mesh->vertices.push_back(point(0, 0, 1));
+    for (int i = 0; i < tess_ph; ++i) mesh->faces.push_back(TriMesh::Face(0, ((i + 1) % tess_ph) + 1, i + 1));
+    for (int j = 0; j < tess_th - 2; ++j) {
+        const int base = 1 + j * tess_ph;
+        for (int i = 0; i < tess_ph; ++i) { const int i1 = (i + 1) % tess_ph; quad(mesh, base + i, base + i1, base + tess_ph + i, base + tess_ph + i1); }
+    }
+    const int base = 1 + (tess_th - 2) * tess_ph;
+    for (int i = 0; i < tess_ph; ++i) mesh->faces.push_back(TriMesh::Face(base + i, base + ((i + 1) % tess_ph), base + tess_ph));
+}
+
+// [-1, 1]^3: the z = -1 face ((tess+1)^2 nodes, x and y running DOWN from +1), tess - 1 rings of 4 tess nodes around the sides (-y, +x, +y, -x side
+// in turn), the z = +1 face (x and y running up); faces: bottom, the four sides ring by ring, top
+static inline void make_cube(TriMesh *mesh, int tess) {
+    using namespace detail;
+    tess = std::max(tess, 1);
+    const int t1 = tess + 1;
+    for (int j = 0; j < t1; ++j) { const float y = 1.0f - 2.0f * j / tess; for (int i = 0; i < t1; ++i) { const float x = 1.0f - 2.0f * i / tess; mesh->vertices.push_back(point(x, y, -1)); } }
+    for (int j = 1; j < tess; ++j) {
+        const float z = -1.0f + 2.0f * j / tess;
+        for (int i = 0; i < tess; ++i) { const float x = -1.0f + 2.0f * i / tess; mesh->vertices.push_back(point(x, -1, z)); }
+        for (int i = 0; i < tess; ++i) { const float y = -1.0f + 2.0f * i / tess; mesh->vertices.push_back(point(1, y, z)); }
+        for (int i = 0; i < tess; ++i) { const float x = 1.0f - 2.0f * i / tess; mesh->vertices.push_back(point(x, 1, z)); }
+        for (int i = 0; i < tess; ++i) { const float y = 1.0f - 2.0f * i / tess; mesh->vertices.push_back(point(-1, y, z)); }
+    }
+    for (int j = 0; j < t1; ++j) { const float y = -1.0f + 2.0f * j / tess; for (int i = 0; i < t1; ++i) { const float x = -1.0f + 2.0f * i / tess; mesh->vertices.push_back(point(x, y, 1)); } }
+    for (int j = 0; j < tess; ++j) for (int i = 0; i < tess; ++i) { const int ind = i + j * t1; quad(mesh, ind, ind + t1, ind + 1, ind + t1 + 1); }
+    const int top = sq(t1) + 4 * tess * (tess - 1);
+    for (int j = 0; j < tess; ++j) {
+        int next = sq(t1) + 4 * tess * (j - 1);
+        for (int side = 0; side < 4; ++side)
+            for (int i = 0; i < tess; ++i) {
+                int ll = next++, lr = ll + 1, ul = ll + 4 * tess, ur = ul + 1;
+                if (j == 0) {                                  // the lower edge lies on the bottom face
+                    if (side == 0) { ll = sq(t1) - 1 - i; lr = ll - 1; }
+                    else if (side == 1) { ll = tess * t1 - i * t1; lr = ll - t1; }
+                    else if (side == 2) { ll = i; lr = i + 1; }
+                    else { ll = tess + i * t1; lr = ll + t1; }
+                }
+                if (j == tess - 1 && side > 0) {               // the upper edge lies on the top face (side 0's does too, but trimesh2 leaves that row to the ring formula)
+                    if (side == 1) { ul = top + tess + i * t1; ur = ul + t1; }
+                    else if (side == 2) { ul = top + sq(t1) - 1 - i; ur = ul - 1; }
+                    else { ul = top + tess * t1 - i * t1; ur = ul - t1; }
+                }
+                if (side == 3 && i == tess - 1) { if (j != 0) lr -= 4 * tess; if (j != tess - 1) ur -= 4 * tess; }      // the ring closes
+                quad(mesh, ll, lr, ul, ur);
+            }
+    }
+    for (int j = 0; j < tess; ++j) for (int i = 0; i < tess; ++i) { const int ind = top + i + j * t1; quad(mesh, ind, ind + 1, ind + t1, ind + t1 + 1); }
+}
+
+// remove.cc: faces / vertices compacted in place, order kept
+static inline void remove_faces(TriMesh *mesh, const std::vector<bool> &gone) {
+    size_t next = 0;
+    for (size_t f = 0; f < mesh->faces.size(); ++f) if (!gone[f]) mesh->faces[next++] = mesh->faces[f];
+    mesh->faces.resize(next);
+    mesh->adjacentfaces.clear(); mesh->across_edge.clear();
+}
+static inline void remove_unused_vertices(TriMesh *mesh) {
+    const size_t nv = mesh->vertices.size();
+    std::vector<int> remap(nv, -1);
+    for (size_t f = 0; f < mesh->faces.size(); ++f) for (int j = 0; j < 3; ++j) remap[mesh->faces[f][j]] = 0;
+    int next = 0;
+    for (size_t v = 0; v < nv; ++v) if (remap[v] == 0) { remap[v] = next; mesh->vertices[next++] = mesh->vertices[v]; }
+    mesh->vertices.resize(next);
+    for (size_t f = 0; f < mesh->faces.size(); ++f) for (int j = 0; j < 3; ++j) mesh->faces[f][j] = remap[mesh->faces[f][j]];
+    mesh->adjacentfaces.clear(); mesh->across_edge.clear();
+}
+// Vec.h:854-857 with operator% (:519-524): half the cross product of the two edges from corner 0, in float
+static inline vec trinorm(const point &v0, const point &v1, const point &v2) {
+    const vec a = v1 - v0, b = v2 - v0;
+    return vec(0.5f * (a[1] * b[2] - a[2] * b[1]), 0.5f * (a[2] * b[0] - a[0] * b[2]), 0.5f * (a[0] * b[1] - a[1] * b[0]));
+}
+
+// `chunks` cubes in a row along +x (2 apart), the faces between neighbours dropped (a face whose normal points along -x / +x), unused vertices
+// dropped per cube, the cubes appended one after the other WITHOUT merging the coincident rim nodes (mclscene's "box" is a beam of one chunk)
+static inline void make_beam(TriMesh *mesh, int tess, int chunks) {
+    for (int b = 0; b < chunks; ++b) {
+        TriMesh box;
+        make_cube(&box, tess);
+        apply_xform(&box, xform::trans(b * 2.f, 0, 0));
+        std::vector<bool> gone(box.faces.size(), false);
+        for (size_t f = 0; f < box.faces.size(); ++f) {
+            const vec n = trinorm(box.vertices[box.faces[f][0]], box.vertices[box.faces[f][1]], box.vertices[box.faces[f][2]]);
+            if (b > 0 && n[0] * -1.f + n[1] * 0.f + n[2] * 0.f > 0.f) gone[f] = true;
+            if (b < chunks - 1 && n[0] * 1.f + n[1] * 0.f + n[2] * 0.f > 0.f) gone[f] = true;
+        }
+        remove_faces(&box, gone);
+        remove_unused_vertices(&box);
+        const int off = (int)mesh->vertices.size();
+        mesh->vertices.insert(mesh->vertices.end(), box.vertices.begin(), box.vertices.end());
+        for (size_t f = 0; f < box.faces.size(); ++f) mesh->faces.push_back(TriMesh::Face(box.faces[f][0] + off, box.faces[f][1] + off, box.faces[f][2] + off));
+    }
+}
+
+// capped cylinder about z in [-1, 1]: bottom centre, tess_h bottom rings (radius growing), tess_h - 1 side rings, tess_h top rings (radius shrinking), top centre
+static inline void make_ccyl(TriMesh *mesh, int tess_th, int tess_h, float r = 1.0f) {
+    using namespace detail;
+    tess_th = std::max(tess_th, 3); tess_h = std::max(tess_h, 1);
+    mesh->vertices.push_back(point(0, 0, -1));
+    for (int j = 1; j <= tess_h; ++j) {
+        const float rr = r * j / tess_h;
+        for (int i = 0; i < tess_th; ++i) { const float th = kTwoPif * i / tess_th; mesh->vertices.push_back(point((float)(rr * dcos(th)), (float)(rr * dsin(th)), -1)); }
+    }
+    const int side_start = (int)mesh->vertices.size();
+    for (int j = 1; j < tess_h; ++j) {
+        const float z = -1.0f + 2.0f * j / tess_h;
+        for (int i = 0; i < tess_th; ++i) { const float th = kTwoPif * i / tess_th; mesh->vertices.push_back(point((float)(r * dcos(th)), (float)(r * dsin(th)), z)); }
+    }
+    const int top_start = (int)mesh->vertices.size();
+    for (int j = tess_h; j > 0; --j) {
+        const float rr = r * j / tess_h;
+        for (int i = 0; i < tess_th; ++i) { const float th = kTwoPif * i / tess_th; mesh->vertices.push_back(point((float)(rr * dcos(th)), (float)(rr * dsin(th)), 1)); }
+    }
+    mesh->vertices.push_back(point(0, 0, 1));
+    for (int i = 0; i < tess_th; ++i) mesh->faces.push_back(TriMesh::Face(0, ((i + 1) % tess_th) + 1, i + 1));
+    for (int j = 1; j < tess_h; ++j) {
+        const int base = 1 + (j - 1) * tess_th;
+        for (int i = 0; i < tess_th; ++i) { const int i1 = (i + 1) % tess_th; quad(mesh, base + tess_th + i1, base + tess_th + i, base + i1, base + i); }
+    }
+    for (int j = 0; j < tess_h; ++j) {
+        const int base = side_start - tess_th + j * tess_th;
+        for (int i = 0; i < tess_th; ++i) { const int i1 = (i + 1) % tess_th; quad(mesh, base + i, base + i1, base + tess_th + i, base + tess_th + i1); }
+    }
+    for (int j = 0; j < tess_h - 1; ++j) {
+        const int base = top_start + j * tess_th;
+        for (int i = 0; i < tess_th; ++i) { const int i1 = (i + 1) % tess_th; quad(mesh, base + tess_th + i1, base + tess_th + i, base + i1, base + i); }
+    }
+    const int base = top_start + (tess_h - 1) * tess_th;
+    for (int i = 0; i < tess_th; ++i) mesh->faces.push_back(TriMesh::Face(base + i, base + ((i + 1) % tess_th), base + tess_th));
+}
+
+// open cylinder: tess_h + 1 rings of tess_th nodes
+static inline void make_cyl(TriMesh *mesh, int tess_th, int tess_h, float r) {
+    using namespace detail;
+    tess_th = std::max(tess_th, 3); tess_h = std::max(tess_h, 1);
+    for (int j = 0; j <= tess_h; ++j) {
+        const float z = -1.0f + 2.0f * j / tess_h;
+        for (int i = 0; i < tess_th; ++i) { const float th = kTwoPif * i / tess_th; mesh->vertices.push_back(point((float)(r * dcos(th)), (float)(r * dsin(th)), z)); }
+    }
+    for (int j = 0; j < tess_h; ++j) {
+        const int base = j * tess_th;
+        for (int i = 0; i < tess_th; ++i) { const int i1 = (i + 1) % tess_th; quad(mesh, base + i, base + i1, base + tess_th + i, base + tess_th + i1); }
+    }
+}
+
+// a cylinder's connectivity with its last ring identified with the first, the nodes moved onto the torus of tube radius inner_rad about the unit circle
+// (outer_rad only sizes the discarded cylinder: "doesn't do anything" as DefaultBuilders.hpp:237 remarks)
+static inline void make_torus(TriMesh *mesh, int tess_th, int tess_ph, float inner_rad, float outer_rad) {
+    using namespace detail;
+    tess_th = std::max(tess_th, 3); tess_ph = std::max(tess_ph, 3);
+    make_cyl(mesh, tess_ph, tess_th, outer_rad);
+    mesh->vertices.resize(mesh->vertices.size() - tess_ph);
+    const int nv = (int)mesh->vertices.size();
+    for (size_t f = 0; f < mesh->faces.size(); ++f) for (int j = 0; j < 3; ++j) mesh->faces[f][j] %= nv;
+    const float r = inner_rad;
+    for (int j = 0; j < tess_th; ++j) {
+        const float th = kTwoPif * j / tess_th;
+        const vec circlepos((float)dcos(th), (float)dsin(th), 0);
+        for (int i = 0; i < tess_ph; ++i) {
+            const float ph = kTwoPif * i / tess_ph;
+            const float cr = cosf(ph) * r, sr = sinf(ph) * r;
+            const vec a(cr * circlepos[0], cr * circlepos[1], cr * circlepos[2]), b(sr * 0.f, sr * 0.f, sr * -1.f);
+            mesh->vertices[i + j * tess_ph] = (circlepos + a) + b;
+        }
+    }
 }
 
 } // namespace trimesh
@@ -418,7 +613,7 @@ private:
     std::string material;
 };
 
-// Scenery whose geometry only mclscene's tessellators can make (sphere, box, cylinder, ...): parameters only.
+// Scenery this loader does not build geometry for (mesh files read by trimesh2, point clouds): parameters only.
 class StaticShape : public BaseObject {
 public:
     StaticShape(std::string type_, std::string mat = "") : type(type_), material(mat) {}
@@ -553,7 +748,7 @@ private:
     }
 };
 
-// DefaultBuilders.hpp:50-304 for the two object types a force can be attached to; everything else -> StaticShape
+// DefaultBuilders.hpp:50-304 for the object types a force can be attached to (plane, the five primitives, tetmesh); everything else -> StaticShape
 static inline std::shared_ptr<BaseObject> default_build_object(Component &obj) {
     const std::string type = parse::to_lower(obj.type);
     trimesh::xform x_form;
@@ -575,6 +770,45 @@ static inline std::shared_ptr<BaseObject> default_build_object(Component &obj) {
         }
         if (noise > 0.0) throw std::runtime_error("\n**Scene Error: object \"" + obj.name + "\": <noise> uses trimesh2's random noisify, which this loader does not carry");
         trimesh::make_sym_plane(tris.get(), width, length);
+        tris->need_tstrips();
+        std::shared_ptr<BaseObject> o(new TriangleMesh(tris, material));
+        o->apply_xform(x_form);
+        return o;
+    }
+    // mclscene's primitives (DefaultBuilders.hpp:83-256): triangle meshes like any other -- ForceBuilder attaches forces to them the same way
+    if (type == "sphere" || type == "box" || type == "cube" || type == "beam" || type == "cylinder" || type == "torus") {
+        std::shared_ptr<trimesh::TriMesh> tris(new trimesh::TriMesh());
+        auto par = [&](const char *key) -> const Param * { const Param *hit = 0; for (size_t i = 0; i < obj.params.size(); ++i) if (parse::to_lower(obj.params[i].tag) == key) hit = &obj.params[i]; return hit; };
+        if (type == "sphere") {
+            double radius = 1.0; trimesh::vec center(0, 0, 0); int tessellation = 1;
+            if (const Param *q = par("radius")) radius = q->as_double();
+            if (const Param *q = par("center")) center = q->as_vec3();
+            if (const Param *q = par("tess")) tessellation = q->as_int();
+            trimesh::make_sphere_polar(tris.get(), tessellation, tessellation);
+            trimesh::apply_xform(tris.get(), trimesh::xform::scale(radius, radius, radius));
+            trimesh::apply_xform(tris.get(), trimesh::xform::trans(center[0], center[1], center[2]));
+        } else if (type == "box" || type == "cube") {      // (trimesh2's make_cube alone "is broken": a beam of one chunk, DefaultBuilders.hpp:122-134)
+            int tess = 3;
+            if (const Param *q = par("tess")) tess = q->as_int();
+            trimesh::make_beam(tris.get(), tess, 1);
+        } else if (type == "beam") {
+            int tess = 3, chunks = 5;
+            if (const Param *q = par("tess")) tess = q->as_int();
+            if (const Param *q = par("chunks")) chunks = q->as_int();
+            trimesh::make_beam(tris.get(), tess, chunks);
+        } else if (type == "cylinder") {
+            float radius = 1.f; int tess_l = 10, tess_c = 10;
+            if (const Param *q = par("tess_l")) tess_l = q->as_int();
+            if (const Param *q = par("tess_c")) tess_c = q->as_int();
+            if (const Param *q = par("radius")) radius = q->as_float();
+            trimesh::make_ccyl(tris.get(), tess_l, tess_c, radius);
+        } else {
+            int tess_th = 50, tess_ph = 20; float inner_rad = 0.25f;
+            if (const Param *q = par("tess_th")) tess_th = q->as_int();
+            if (const Param *q = par("tess_ph")) tess_ph = q->as_int();
+            if (const Param *q = par("inner_radius")) inner_rad = q->as_float();
+            trimesh::make_torus(tris.get(), tess_th, tess_ph, inner_rad, 1.f);
+        }
         tris->need_tstrips();
         std::shared_ptr<BaseObject> o(new TriangleMesh(tris, material));
         o->apply_xform(x_form);

@@ -33,8 +33,9 @@ SCENES = {
     "plinko": ("scenes/plinkopony/plinko.xml", "plinko", 3),
     "two_bodies": ("scenes/custom/two_bodies.xml", "none", 0),
     "uniform_nh": ("scenes/custom/uniform_nh.xml", "none", 0),
+    "shapes": ("scenes/custom/shapes.xml", "none", 2),      # round 5: sphere / box / beam / cylinder / torus as dynamic objects
 }
-DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b")
+DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b", "ball", "crate", "girder", "can", "ring")
 
 
 def child(name):
