@@ -16,8 +16,9 @@
 // transform is applied in double and rounded back to float per coordinate, and the
 // same libstdc++ stream conversions parse and print the numbers.  What is NOT here:
 // rendering data (normals, tstrips, textures, materials, lights, cameras, BVH), trimesh2's
-// ply/obj readers ("trimesh" objects from files) and point clouds: such objects are accepted
-// as static scenery (their parameters are kept); giving one a <Force> is an error.
+// readers for mesh files other than Wavefront OBJ (ply, off, 3ds, stl ...) and point clouds: such
+// objects are accepted as static scenery (their parameters are kept); giving one a <Force> is an error.
+//   trimesh: <File>.obj                          (trimesh2 libsrc/TriMesh_io.cc:232-337,736-788,1352-1407) -- round 5
 //   sphere / box / beam / cylinder / torus       (mclscene DefaultBuilders.hpp:83-256 over trimesh2 TriMeshBuilder.h:220-556,
 //                                                 libsrc/remove.cc) -- round 5: tessellated like the reference does, forces attach
 //
@@ -28,6 +29,8 @@
 #include <cctype>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <strings.h>
 #include <fstream>
 #include <functional>
 #include <iostream>
@@ -400,6 +403,68 @@ static inline void make_torus(TriMesh *mesh, int tess_th, int tess_ph, float inn
             mesh->vertices[i + j * tess_ph] = (circlepos + a) + b;
         }
     }
+}
+
+
+// ---- "trimesh" objects from a Wavefront OBJ file (trimesh2 libsrc/TriMesh_io.cc: read_helper :232-337, read_obj :736-788, tess :1374-1407,
+// skip_comments :1352-1370) -- the one mesh-file format of trimesh2's reader this loader carries.  Same parsing: the file type is sniffed from
+// the first byte ('#', or one of v u f g s o); after a leading '#' ONE word is consumed and the rest of that line is read as an ordinary line;
+// `v x y z` through sscanf("%f %f %f") into float coordinates; `f` / `t` lines take the integer at the start of every whitespace-separated
+// token (so `f 1/2/3 4/5/6 ...` reads the position indices), 1-based or negative (relative to the vertices read so far); quads are cut along
+// their shorter diagonal (float distances, ties: the 1-3 diagonal), larger polygons as a fan from their first corner; lines are read in pieces of
+// at most 1023 bytes like fgets(buf, 1024).  Indices outside the vertex list are an error here (trimesh2's check_ind_range warns and guesses).
+static inline bool read_obj_file(const char *filename, TriMesh *mesh, std::string *why) {
+    FILE *f = std::fopen(filename, "rb");
+    if (!f) { if (why) *why = std::string("cannot open ") + filename; return false; }
+    bool ok = true;
+    int c = std::fgetc(f);
+    if (c == '#') { char word[1025]; if (std::fscanf(f, "%1024s", word) != 1) word[0] = 0; }
+    else if (c == 'v' || c == 'u' || c == 'f' || c == 'g' || c == 's' || c == 'o') std::ungetc(c, f);
+    else { if (why) *why = std::string(filename) + ": not a Wavefront OBJ file (the other formats of trimesh2's reader -- ply, off, 3ds, stl, sm, vvd, ray -- are not carried)"; std::fclose(f); return false; }
+    std::vector<int> corners;
+    char buf[1024];
+    while (ok) {
+        bool in_comment = false;                               // skip_comments: blank space and '#' ... end of line
+        for (;;) {
+            c = std::fgetc(f);
+            if (c == EOF) break;
+            if (in_comment) { if (c == '\n') in_comment = false; }
+            else if (c == '#') in_comment = true;
+            else if (!std::isspace(c)) { std::ungetc(c, f); break; }
+        }
+        if (c == EOF || std::feof(f)) break;
+        if (!std::fgets(buf, 1024, f)) { ok = false; break; }
+        auto is = [&](const char *t) { return strncasecmp(buf, t, std::strlen(t)) == 0; };
+        if (is("v ") || is("v\t")) {
+            float x, y, z;
+            if (std::sscanf(buf + 1, "%f %f %f", &x, &y, &z) != 3) { ok = false; break; }
+            mesh->vertices.push_back(point(x, y, z));
+        } else if (is("f ") || is("f\t") || is("t ") || is("t\t")) {
+            corners.clear();
+            char *q = buf;
+            for (;;) {
+                while (*q && *q != '\n' && !std::isspace((unsigned char)*q)) ++q;
+                while (*q && std::isspace((unsigned char)*q)) ++q;
+                int idx;
+                if (std::sscanf(q, " %d", &idx) != 1) break;
+                corners.push_back(idx < 0 ? idx + (int)mesh->vertices.size() : idx - 1);
+            }
+            for (size_t k = 0; k < corners.size(); ++k) if (corners[k] < 0 || corners[k] >= (int)mesh->vertices.size()) { if (why) *why = std::string(filename) + ": face index outside the vertices read so far"; ok = false; }
+            if (!ok) break;
+            const size_t nc = corners.size();
+            if (nc == 3) mesh->faces.push_back(TriMesh::Face(corners[0], corners[1], corners[2]));
+            else if (nc == 4) {
+                const vec d02 = mesh->vertices[corners[0]] - mesh->vertices[corners[2]], d13 = mesh->vertices[corners[1]] - mesh->vertices[corners[3]];
+                const int i = (len2(d02) < len2(d13)) ? 0 : 1;
+                mesh->faces.push_back(TriMesh::Face(corners[i], corners[(i + 1) % 4], corners[(i + 2) % 4]));
+                mesh->faces.push_back(TriMesh::Face(corners[i], corners[(i + 2) % 4], corners[(i + 3) % 4]));
+            } else for (size_t k = 2; k < nc; ++k) mesh->faces.push_back(TriMesh::Face(corners[0], corners[k - 1], corners[k]));
+        }
+    }
+    std::fclose(f);
+    if (ok && mesh->vertices.empty()) { ok = false; if (why) *why = std::string(filename) + ": no vertices"; }
+    if (!ok && why && why->empty()) *why = std::string("error reading ") + filename;
+    return ok;
 }
 
 } // namespace trimesh
@@ -809,6 +874,22 @@ static inline std::shared_ptr<BaseObject> default_build_object(Component &obj) {
             if (const Param *q = par("inner_radius")) inner_rad = q->as_float();
             trimesh::make_torus(tris.get(), tess_th, tess_ph, inner_rad, 1.f);
         }
+        tris->need_tstrips();
+        std::shared_ptr<BaseObject> o(new TriangleMesh(tris, material));
+        o->apply_xform(x_form);
+        return o;
+    }
+    if (type == "trimesh") {      // DefaultBuilders.hpp:258-285: read the file, drop unreferenced vertices
+        std::string filename = "";
+        for (size_t i = 0; i < obj.params.size(); ++i) if (parse::to_lower(obj.params[i].tag) == "file") filename = obj.params[i].as_string();
+        if (!filename.size()) throw std::runtime_error("\n**TriangleMesh Error for obj " + obj.name + ": No file specified");
+        std::shared_ptr<trimesh::TriMesh> tris(new trimesh::TriMesh());
+        std::string why;
+        if (!trimesh::read_obj_file(filename.c_str(), tris.get(), &why)) {
+            if (!obj.exists("force")) return std::shared_ptr<BaseObject>(new StaticShape(type, material));      // scenery in a format this loader does not read: parameters only, as before
+            throw std::runtime_error("\n**TriangleMesh Error for obj " + obj.name + ": failed to load file " + filename + " (" + why + ")");
+        }
+        trimesh::remove_unused_vertices(tris.get());
         tris->need_tstrips();
         std::shared_ptr<BaseObject> o(new TriangleMesh(tris, material));
         o->apply_xform(x_form);

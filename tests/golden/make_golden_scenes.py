@@ -34,8 +34,9 @@ SCENES = {
     "two_bodies": ("scenes/custom/two_bodies.xml", "none", 0),
     "uniform_nh": ("scenes/custom/uniform_nh.xml", "none", 0),
     "shapes": ("scenes/custom/shapes.xml", "none", 2),      # round 5: sphere / box / beam / cylinder / torus as dynamic objects
+    "objmesh": ("scenes/custom/objmesh.xml", "none", 2),    # round 5: a "trimesh" object from a Wavefront OBJ file
 }
-DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b", "ball", "crate", "girder", "can", "ring")
+DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b", "ball", "crate", "girder", "can", "ring", "patch")
 
 
 def child(name):

@@ -29,7 +29,8 @@ SCENES = {
     "plinko": ("scenes/plinkopony/plinko.xml", "plinko"),
     "two_bodies": ("scenes/custom/two_bodies.xml", "none"),
     "uniform_nh": ("scenes/custom/uniform_nh.xml", "none"),
-    "shapes": ("scenes/custom/shapes.xml", "none"),      # sphere / box / beam / cylinder / torus tessellated like mclscene does, with forces on them
+    "shapes": ("scenes/custom/shapes.xml", "none"),
+    "objmesh": ("scenes/custom/objmesh.xml", "none"),    # a "trimesh" object read from a Wavefront OBJ file (quads, a pentagon, v/vt/vn and relative indices, an unused vertex)      # sphere / box / beam / cylinder / torus tessellated like mclscene does, with forces on them
 }
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -143,11 +144,21 @@ def test_loader_errors(pkg, tmp_path):
                    '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
     assert r.returncode == 2 and "must specify mass" in r.stderr
-    # geometry this loader does not build (a mesh file read by trimesh2) cannot carry a force; the primitives can (scene "shapes")
-    bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="x.obj"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
+    # geometry this loader does not build (a point cloud, a mesh file that is not Wavefront OBJ) cannot carry a force; the primitives and OBJ meshes can
+    bad.write_text('<mclScene><Object name="s" type="pointcloud"><File value="x.ply"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
                    '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
     assert r.returncode == 2 and "builds geometry only for tetmesh, plane, sphere, box, beam, cylinder and torus" in r.stderr
+    (tmp_path / "m.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
+    for fname, msg in (("missing.obj", "cannot open"), ("m.ply", "not a Wavefront OBJ file")):
+        bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="%s"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
+                       '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>' % fname)
+        r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
+        assert r.returncode == 2 and "failed to load file" in r.stderr and msg in r.stderr, r.stderr
+    # ... while the same file as static scenery (no force) is accepted: parameters only
+    bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="m.ply"/></Object></mclScene><admmelastic></admmelastic>')
+    r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
+    assert "failed to load file" not in r.stderr      # (a scene without any dynamic object: whatever the solver says about an empty system, the loader did not throw)
     # component without name/type
     bad.write_text('<mclScene><Object type="plane"/></mclScene>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
@@ -177,7 +188,7 @@ def run_scene(pkg, tmp_path, name, frames):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 1e-10), ("bunnyexpand", 1e-10), ("shapes", 1e-9)])
+@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 1e-10), ("bunnyexpand", 1e-10), ("shapes", 1e-9), ("objmesh", 1e-9)])
 def test_shipped_scene_trajectories(pkg, tmp_path, name, tol):
     """The sample scenes, loaded from their XML by the headless SimContext and stepped on the GPU, against
     the reference's SimContext + System on the same files.  windyflag without wind / plinko contain no
