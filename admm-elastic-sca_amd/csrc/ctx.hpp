@@ -170,6 +170,7 @@ struct admm_hip_ctx {
     // class API frame boundary of small systems: no DMA, the permutation kernels read / write this page-locked buffer ([x | v], caller's order)
     int state_direct_max_nodes = 12288; double *h_state = nullptr, *h_state_dev = nullptr; size_t h_state_cap = 0; int *d_iperm = nullptr; hipEvent_t state_in_ev = nullptr; bool state_in_pending = false;
     std::vector<std::pair<const char *, size_t> > pinned;      // host spans page-locked through admm_hip_pin_host (the zero-copy state kernels check them)
+    std::vector<double> bounce;                                 // upload_state / download_state of a vector that is page-locked only in part (neither mappable nor DMA-able as one span)
     bool tree_search = true;                       // pick the elimination tree of mid-size systems by the sweeps' cost model (ADMM_HIP_TREE_SEARCH=0: the rule-based tree)
     bool top_bwd_needed_only = true;              // subtree sharding: the backward sweep over the replicated top skips the separators this rank never reads (ADMM_HIP_TOP_BWD_ALL=1: all of them)
     int root_fuse_k = 2048;                       // roots of at most that many columns: t is gathered inside the product kernel (ADMM_HIP_ROOT_FUSE_K; 0 = never)
@@ -212,7 +213,9 @@ namespace admm_lib {
 
 int fail(admm_hip_ctx *c, int code, const char *fmt, ...);      // (comm.cpp)
 
-#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, ADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+// (a failed call also leaves HIP's sticky last-error set: cleared here, so that an unrelated hipGetLastError() check later -- in this context or
+//  another one of the process -- does not report this failure a second time as its own)
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(ctx, ADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
 
 template <class T> int dalloc(admm_hip_ctx *ctx, T **p, size_t n) {
     *p = nullptr;
