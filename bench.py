@@ -532,9 +532,9 @@ def main():
     valu = None
     sweeps = None
     bound = "hbm"
-    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r04/pmc_1M.json"))
+    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r05/pmc_1M.json"))
     if not os.path.exists(os.path.join(ROOT, pmc_file)):
-        pmc_file = os.path.join("profiles", "r03/pmc_1M.json")
+        pmc_file = os.path.join("profiles", "r04/pmc_1M.json")
     pmc_stamp_ok = None      # True / False: the counter file carries the hash of the sources it was collected on (None: an unstamped, older file)
     try:
         stamp = json.load(open(os.path.join(ROOT, pmc_file))).get("csrc_sha256")
@@ -573,9 +573,9 @@ def main():
                 valu.update(measured_roof(pm, sec))
                 bound = "valu"
         if a.config == "mixed" and world == 1 and dom.startswith("project_multi_kernel"):      # the scene's one-launch local step: counters of tools/pmc_collect.sh with PMC_MIXED=1
-            pmc_file = os.path.join("profiles", "r04", "pmc_mixed.json")
+            pmc_file = os.path.join("profiles", "r05", "pmc_mixed.json")
             if not os.path.exists(os.path.join(ROOT, pmc_file)):
-                pmc_file = os.path.join("profiles", "r03", "pmc_mixed.json")
+                pmc_file = os.path.join("profiles", "r04", "pmc_mixed.json")
             kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
             pm = kern[[k for k in kern if "project_multi_kernel" in k][0]]
             traffic = (2.0 * pm["FETCH_SIZE"]["per_launch"] + pm["WRITE_SIZE"]["per_launch"]) * 1024.0

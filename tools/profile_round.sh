@@ -25,6 +25,7 @@ rm -rf /tmp/prof_trace
 (cd /tmp && ADMM_HIP_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python3 $GRAFT_REPO_ROOT/tools/run_steps.py 32 32 163 1 > /dev/null 2>&1)
 python tools/level_trace.py /tmp/prof_trace >> $O/level_trace_1M.txt 2>&1
 tail -12 $O/level_trace_1M.txt
+PMC_MIXED=1 bash tools/pmc_collect.sh >> $O/pmc_collect.log 2>&1; cp gpurun_out/pmc_mixed.json profiles/$R/pmc_mixed.json; cp gpurun_out/pmc_mixed.json $O/pmc_mixed.json
 python bench.py --config mixed --no-extras > $O/bench_mixed.json 2>/dev/null
 tail -1 $O/bench_mixed.json | cut -c1-200
 # 5. what every RANK of a 2 / 4 / 8-rank run computes per iteration, real physics, one rank on the GPU at a time (tools/ranks_one_gpu.py)
