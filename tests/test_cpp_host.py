@@ -365,6 +365,15 @@ def test_reference_programs_run_on_the_gpu(pkg, tmp_path):
     pkg.lib()
     r = subprocess.run([os.path.join(REF_BIN, "singletet_hip")], capture_output=True, text=True)
     assert r.returncode == 0 and "Node 4 x: 171.571" in r.stdout, r.stdout + r.stderr
+    # the same UNCHANGED binary under a launcher's environment: ADMM_HIP_RANKS_FROM_ENV=1 makes System::initialize() take rank / world / GPU
+    # from it (a one-rank launch here: the multi-rank form needs one GPU per rank for RCCL) -- same answer; a rank outside the world is refused
+    env = dict(os.environ, ADMM_HIP_RANKS_FROM_ENV="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([os.path.join(REF_BIN, "singletet_hip")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "Node 4 x: 171.571" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, ADMM_HIP_RANKS_FROM_ENV="1", RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29777", ADMM_HIP_RCCL_ID_FILE=str(tmp_path / "id"))
+    env.pop("ADMM_HIP_RCCL_LIB", None)
+    r = subprocess.run([os.path.join(REF_BIN, "singletet_hip")], capture_output=True, text=True, env=dict(env, RANK="5"), timeout=120)
+    assert "171.571" not in r.stdout and "shard.rank 5 outside [0, 2)" in r.stderr, r.stdout + r.stderr
     r = subprocess.run([os.path.join(REF_BIN, "singlenode_hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     for want in ("-9.8", "-29.4", "-58.8", "-98"):
