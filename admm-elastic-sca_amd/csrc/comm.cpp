@@ -93,6 +93,7 @@ extern "C" {
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user) {
     if (!ctx) return ADMM_ERR_ARG;
     ctx->allreduce = fn; ctx->allreduce_user = user;
+    ctx->graphs_stale = true;
     return ADMM_OK;
 }
 
@@ -143,8 +144,9 @@ int admm_hip_rccl_init(admm_hip_ctx *ctx, const void *id128, int rank, int world
     void *comm = nullptr;
     const int rc = R->CommInitRank(&comm, world, id, rank);
     if (rc != 0 || !comm) return fail(ctx, ADMM_ERR_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device_id, R->GetErrorString ? R->GetErrorString(rc) : "?");
-    if (ctx->rccl_comm && ctx->rccl_owned) (void)R->CommDestroy(ctx->rccl_comm);
+    if (ctx->rccl_comm && ctx->rccl_owned) { (void)hipStreamSynchronize(ctx->stream); (void)R->CommDestroy(ctx->rccl_comm); }
     ctx->rccl_comm = comm; ctx->rccl_owned = true;
+    ctx->graphs_stale = true;      // (a captured multi-GPU iteration names the communicator it was captured with)
     return ADMM_OK;
 }
 int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm) {
@@ -152,8 +154,9 @@ int admm_hip_set_rccl_comm(admm_hip_ctx *ctx, void *nccl_comm) {
     std::string why;
     RcclApi *R = rccl_api(&why);
     if (nccl_comm && !R) return fail(ctx, ADMM_ERR_COMM, "%s", why.c_str());
-    if (ctx->rccl_comm && ctx->rccl_owned && R) (void)R->CommDestroy(ctx->rccl_comm);
+    if (ctx->rccl_comm && ctx->rccl_owned && R) { if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); (void)R->CommDestroy(ctx->rccl_comm); }
     ctx->rccl_comm = nccl_comm; ctx->rccl_owned = false;
+    ctx->graphs_stale = true;
     return ADMM_OK;
 }
 int admm_hip_rccl_async_error(admm_hip_ctx *ctx, int *nccl_result) {

@@ -184,6 +184,7 @@ struct admm_hip_ctx {
     int bwd_nw_min_cols = 4096, fwd_nw16_max_tiles = 512;
     int fwd_nw4_kmax = 200, fwd_nw8_kmax = 400;   // forward sweep: levels whose widest supernode has at most this many columns run 4 / 8 waves per tile (ADMM_HIP_FWD_NW4 / _NW8)
     int64_t graph_launches = 0;               // hipGraphLaunch calls so far (admm_hip_debug_graph_state)
+    bool graphs_stale = false;                // a captured iteration holds the communicator it was captured with: set when that changes (comm.cpp), honoured by the next admm_hip_step
     bool graph_comm = false;                  // ADMM_HIP_GRAPH_COMM=1: also capture the multi-GPU iteration (ncclAllReduce inside the graph)
     // residual tracking / early exit (off by default)
     bool res_on = false, res_ready = false;

@@ -101,7 +101,13 @@ for variant in ("hook", "rccl-eager", "rccl-graph"):
     for f in range(frames):
         s.step(iters)
         xs.append(s.m_x.copy())
+    g_before = s.graph_state()
+    if variant != "hook":          # a NEW communicator replaces the one the iteration was captured with: the graphs must be captured again, not replayed
+        s.rccl_init(s.rccl_unique_id(), 0, 1)
+    s.step(iters); xs.append(s.m_x.copy())
     vs = s.m_v.copy()
+    if variant == "rccl-graph":
+        assert g_before["iter_graph"] and s.graph_state()["iter_graph"] and s.graph_state()["graph_launches"] > g_before["graph_launches"]
     if variant != "hook":
         assert s.rccl_async_error() == 0
         host = np.array([1.5, -2.25, 1e300])
@@ -110,14 +116,14 @@ for variant in ("hook", "rccl-eager", "rccl-graph"):
     g = s.graph_state()
     res[variant] = dict(x=xs, v=vs, g=g, calls=calls[0])
     if variant == "hook":
-        assert calls[0] >= frames * iters and not g["iter_graph"], (calls, g)     # a host hook cannot be captured
+        assert calls[0] >= (frames + 1) * iters and not g["iter_graph"], (calls, g)     # a host hook cannot be captured
     if variant == "rccl-eager":
         assert not g["iter_graph"] and g["graph_launches"] == 0, g
     if variant == "rccl-graph":
         assert g["iter_graph"] and g["graph_launches"] >= frames, g               # ncclAllReduce inside the captured iteration
     del s
 for variant in ("rccl-eager", "rccl-graph"):
-    for f in range(frames):
+    for f in range(frames + 1):
         assert np.array_equal(res[variant]["x"][f], res["hook"]["x"][f]), (variant, f, np.abs(res[variant]["x"][f] - res["hook"]["x"][f]).max())
     assert np.array_equal(res[variant]["v"], res["hook"]["v"]), variant
 fin = all(np.isfinite(x).all() for x in res["hook"]["x"])
