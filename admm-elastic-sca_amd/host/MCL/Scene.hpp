@@ -16,9 +16,9 @@
 // transform is applied in double and rounded back to float per coordinate, and the
 // same libstdc++ stream conversions parse and print the numbers.  What is NOT here:
 // rendering data (normals, tstrips, textures, materials, lights, cameras, BVH), trimesh2's
-// readers for mesh files other than Wavefront OBJ (ply, off, 3ds, stl ...) and point clouds: such
+// readers for mesh files other than Wavefront OBJ and PLY (off, 3ds, stl, sm ...) and point clouds: such
 // objects are accepted as static scenery (their parameters are kept); giving one a <Force> is an error.
-//   trimesh: <File>.obj                          (trimesh2 libsrc/TriMesh_io.cc:232-337,736-788,1352-1407) -- round 5
+//   trimesh: <File> .obj / .ply                  (trimesh2 libsrc/TriMesh_io.cc:232-337,342-556,736-788,870-1150,1243-1407) -- round 5
 //   sphere / box / beam / cylinder / torus       (mclscene DefaultBuilders.hpp:83-256 over trimesh2 TriMeshBuilder.h:220-556,
 //                                                 libsrc/remove.cc) -- round 5: tessellated like the reference does, forces attach
 //
@@ -407,32 +407,46 @@ static inline void make_torus(TriMesh *mesh, int tess_th, int tess_ph, float inn
 
 
 // ---- "trimesh" objects from a Wavefront OBJ file (trimesh2 libsrc/TriMesh_io.cc: read_helper :232-337, read_obj :736-788, tess :1374-1407,
-// skip_comments :1352-1370) -- the one mesh-file format of trimesh2's reader this loader carries.  Same parsing: the file type is sniffed from
+// skip_comments :1352-1370); PLY below.  Same parsing: the file type is sniffed from
 // the first byte ('#', or one of v u f g s o); after a leading '#' ONE word is consumed and the rest of that line is read as an ordinary line;
 // `v x y z` through sscanf("%f %f %f") into float coordinates; `f` / `t` lines take the integer at the start of every whitespace-separated
 // token (so `f 1/2/3 4/5/6 ...` reads the position indices), 1-based or negative (relative to the vertices read so far); quads are cut along
 // their shorter diagonal (float distances, ties: the 1-3 diagonal), larger polygons as a fan from their first corner; lines are read in pieces of
 // at most 1023 bytes like fgets(buf, 1024).  Indices outside the vertex list are an error here (trimesh2's check_ind_range warns and guesses).
-static inline bool read_obj_file(const char *filename, TriMesh *mesh, std::string *why) {
-    FILE *f = std::fopen(filename, "rb");
-    if (!f) { if (why) *why = std::string("cannot open ") + filename; return false; }
+// an n-gon -> triangles (TriMesh_io.cc tess :1374-1407): quads along their shorter diagonal (float distances, ties: the 1-3 diagonal), larger polygons as a fan
+static inline void tess_polygon(const std::vector<point> &verts, const std::vector<int> &c, std::vector<TriMesh::Face> &tris) {
+    const size_t nc = c.size();
+    if (nc < 3) return;
+    if (nc == 3) { tris.push_back(TriMesh::Face(c[0], c[1], c[2])); return; }
+    if (nc == 4) {
+        const vec d02 = verts[c[0]] - verts[c[2]], d13 = verts[c[1]] - verts[c[3]];
+        const int i = (len2(d02) < len2(d13)) ? 0 : 1;
+        tris.push_back(TriMesh::Face(c[i], c[(i + 1) % 4], c[(i + 2) % 4]));
+        tris.push_back(TriMesh::Face(c[i], c[(i + 2) % 4], c[(i + 3) % 4]));
+        return;
+    }
+    for (size_t k = 2; k < nc; ++k) tris.push_back(TriMesh::Face(c[0], c[k - 1], c[k]));
+}
+// skip_comments (:1352-1370): blank space and '#' ... end of line
+static inline void skip_comments(FILE *f) {
+    bool in_comment = false;
+    for (;;) {
+        const int c = std::fgetc(f);
+        if (c == EOF) return;
+        if (in_comment) { if (c == '\n') in_comment = false; }
+        else if (c == '#') in_comment = true;
+        else if (!std::isspace(c)) { std::ungetc(c, f); return; }
+    }
+}
+
+static inline bool read_obj_body(FILE *f, const char *filename, TriMesh *mesh, std::string *why) {
     bool ok = true;
-    int c = std::fgetc(f);
-    if (c == '#') { char word[1025]; if (std::fscanf(f, "%1024s", word) != 1) word[0] = 0; }
-    else if (c == 'v' || c == 'u' || c == 'f' || c == 'g' || c == 's' || c == 'o') std::ungetc(c, f);
-    else { if (why) *why = std::string(filename) + ": not a Wavefront OBJ file (the other formats of trimesh2's reader -- ply, off, 3ds, stl, sm, vvd, ray -- are not carried)"; std::fclose(f); return false; }
     std::vector<int> corners;
     char buf[1024];
     while (ok) {
-        bool in_comment = false;                               // skip_comments: blank space and '#' ... end of line
-        for (;;) {
-            c = std::fgetc(f);
-            if (c == EOF) break;
-            if (in_comment) { if (c == '\n') in_comment = false; }
-            else if (c == '#') in_comment = true;
-            else if (!std::isspace(c)) { std::ungetc(c, f); break; }
-        }
-        if (c == EOF || std::feof(f)) break;
+        skip_comments(f);
+        { const int c = std::fgetc(f); if (c == EOF) break; std::ungetc(c, f); }
+        if (std::feof(f)) break;
         if (!std::fgets(buf, 1024, f)) { ok = false; break; }
         auto is = [&](const char *t) { return strncasecmp(buf, t, std::strlen(t)) == 0; };
         if (is("v ") || is("v\t")) {
@@ -451,20 +465,181 @@ static inline bool read_obj_file(const char *filename, TriMesh *mesh, std::strin
             }
             for (size_t k = 0; k < corners.size(); ++k) if (corners[k] < 0 || corners[k] >= (int)mesh->vertices.size()) { if (why) *why = std::string(filename) + ": face index outside the vertices read so far"; ok = false; }
             if (!ok) break;
-            const size_t nc = corners.size();
-            if (nc == 3) mesh->faces.push_back(TriMesh::Face(corners[0], corners[1], corners[2]));
-            else if (nc == 4) {
-                const vec d02 = mesh->vertices[corners[0]] - mesh->vertices[corners[2]], d13 = mesh->vertices[corners[1]] - mesh->vertices[corners[3]];
-                const int i = (len2(d02) < len2(d13)) ? 0 : 1;
-                mesh->faces.push_back(TriMesh::Face(corners[i], corners[(i + 1) % 4], corners[(i + 2) % 4]));
-                mesh->faces.push_back(TriMesh::Face(corners[i], corners[(i + 2) % 4], corners[(i + 3) % 4]));
-            } else for (size_t k = 2; k < nc; ++k) mesh->faces.push_back(TriMesh::Face(corners[0], corners[k - 1], corners[k]));
+            tess_polygon(mesh->vertices, corners, mesh->faces);
         }
     }
-    std::fclose(f);
-    if (ok && mesh->vertices.empty()) { ok = false; if (why) *why = std::string(filename) + ": no vertices"; }
     if (!ok && why && why->empty()) *why = std::string("error reading ") + filename;
     return ok;
+}
+
+// ---- PLY (TriMesh_io.cc read_ply :342-556 with read_verts_asc / _bin, read_faces_asc / _bin, ply_type_len, check_need_swap): ascii and binary of
+// either byte order; the vertex element's position is three consecutive floats starting at `property float x`; whatever other scalar properties and
+// whatever elements precede the vertices or sit between vertices and faces are skipped by their declared sizes (words in ascii files); faces are
+// `property list <count type> <index type> vertex_ind...` lists -- the count read as 1 or 4 bytes, the indices ALWAYS as 4-byte integers, like
+// trimesh2 does -- plus other scalar properties; polygons are cut like OBJ faces.  Triangle strips and range grids are not carried.
+namespace detail {
+inline int ply_type_len(const char *t, bool binary) {
+    auto is = [&](const char *w) { return strncasecmp(t, w, std::strlen(w)) == 0; };
+    if (is("char") || is("uchar") || is("int8") || is("uint8")) return 1;
+    if (is("short") || is("ushort") || is("int16") || is("uint16")) return binary ? 2 : 1;
+    if (is("int") || is("uint") || is("float") || is("int32") || is("uint32") || is("float32")) return binary ? 4 : 1;
+    if (is("double") || is("float64")) return binary ? 8 : 1;
+    return 0;
+}
+inline void swap32(void *p) { unsigned char *c = (unsigned char *)p; std::swap(c[0], c[3]); std::swap(c[1], c[2]); }
+} // namespace detail
+
+static inline bool read_ply_body(FILE *f, const char *filename, TriMesh *mesh, std::string *why) {
+    using namespace detail;
+    char buf[1024];
+    auto fail = [&](const char *msg) { if (why) *why = std::string(filename) + ": " + msg; return false; };
+    auto line = [&]() { return std::fgets(buf, 1024, f) != 0; };
+    auto is = [&](const char *t) { return strncasecmp(buf, t, std::strlen(t)) == 0; };
+    const int one = 1; const bool little = *(const unsigned char *)&one != 0;
+    if (!line()) return fail("truncated header");
+    while (buf[0] && std::isspace((unsigned char)buf[0])) if (!line()) return fail("truncated header");
+    bool binary = false, need_swap = false;
+    if (is("format binary_big_endian 1.0")) { binary = true; need_swap = little; }
+    else if (is("format binary_little_endian 1.0")) { binary = true; need_swap = !little; }
+    else if (!is("format ascii 1.0")) return fail("unknown ply format or version");
+    if (!line()) return fail("truncated header");
+    while (is("obj_info") || is("comment")) if (!line()) return fail("truncated header");
+    // elements ahead of the vertices / between vertices and faces: sized and skipped
+    auto skip_elements = [&](int &skip, std::initializer_list<const char *> stops) -> bool {
+        for (;;) {
+            for (const char *st : stops) if (is(st)) return true;
+            char name[1024]; int nelem = 0, elem_len = 0;
+            std::sscanf(buf, "element %1023s %d", name, &nelem);
+            if (!line()) return false;
+            while (is("property")) { const int tl = ply_type_len(buf + 9, binary); if (!tl) return false; elem_len += tl; if (!line()) return false; }
+            skip += nelem * elem_len;
+        }
+    };
+    int skip1 = 0, skip2 = 0, nverts = 0, nfaces = 0;
+    if (!skip_elements(skip1, {"end_header", "element vertex"})) return fail("unsupported property ahead of the vertices");
+    if (std::sscanf(buf, "element vertex %d\n", &nverts) != 1) return fail("expected \"element vertex\"");
+    int vert_len = 0, vert_pos = -1, vert_norm = -1, vert_color = -1, vert_conf = -1; bool float_color = false;
+    if (!line()) return fail("truncated header");
+    while (is("property")) {
+        if (is("property float x") || is("property float32 x")) vert_pos = vert_len;
+        if (is("property float nx") || is("property float32 nx")) vert_norm = vert_len;
+        if (is("property uchar diffuse_red") || is("property uint8 diffuse_red") || is("property uchar red") || is("property uint8 red")) vert_color = vert_len;
+        if (is("property float diffuse_red") || is("property float32 diffuse_red") || is("property float red") || is("property float32 red")) { vert_color = vert_len; float_color = true; }
+        if (is("property float confidence") || is("property float32 confidence")) vert_conf = vert_len;
+        const int tl = ply_type_len(buf + 9, binary);
+        if (!tl) return fail("unsupported vertex property");
+        vert_len += tl;
+        if (!line()) return fail("truncated header");
+    }
+    if (!skip_elements(skip2, {"end_header", "element face", "element tristrips", "element range_grid"})) return fail("unsupported property between vertices and faces");
+    int face_len = 0, face_count = -1, face_idx = -1;
+    if (is("element face")) {
+        if (std::sscanf(buf, "element face %d\n", &nfaces) != 1) return fail("bad face element");
+        if (!line()) return fail("truncated header");
+        while (is("property")) {
+            char ct[256], it[256];
+            if (std::sscanf(buf, "property list %255s %255s vertex_ind", ct, it) == 2) {
+                const int cl = ply_type_len(ct, binary), il = ply_type_len(it, binary);
+                if (cl && il) { face_count = face_len; face_idx = face_len + cl; face_len += cl; }
+            } else { const int tl = ply_type_len(buf + 9, binary); if (!tl) return fail("unsupported face property"); face_len += tl; }
+            if (!line()) return fail("truncated header");
+        }
+    } else if (is("element tristrips") || is("element range_grid")) return fail("triangle strips / range grids are not carried by this loader");
+    while (!is("end_header")) if (!line()) return fail("no end_header");
+    // ---- data ----
+    auto skip_data = [&](int n) { if (binary) std::fseek(f, n, SEEK_CUR); else for (int i = 0; i < n; ++i) if (std::fscanf(f, "%1023s", buf) != 1) break; };
+    if (skip1) skip_data(skip1);
+    if (nverts <= 0 || vert_pos < 0 || vert_len < (binary ? 12 : 3)) return fail("no float x y z vertices");
+    const size_t v0 = mesh->vertices.size();
+    mesh->vertices.resize(v0 + nverts);
+    if (binary) {
+        std::vector<unsigned char> rec(vert_len);
+        for (int i = 0; i < nverts; ++i) {
+            if (std::fread(rec.data(), vert_len, 1, f) != 1) return fail("truncated vertex data");
+            float q[3]; std::memcpy(q, &rec[vert_pos], 12);
+            if (i == 0) {      // check_need_swap: a first vertex that only makes sense in the other byte order flips the declared one
+                auto sane = [](const float *w) { return w[0] > -1.0e10f && w[0] < 1.0e10f && w[1] > -1.0e10f && w[1] < 1.0e10f && w[2] > -1.0e10f && w[2] < 1.0e10f; };
+                float t[3] = {q[0], q[1], q[2]};
+                if (need_swap) for (int k = 0; k < 3; ++k) swap32(&t[k]);
+                if (!sane(t)) { for (int k = 0; k < 3; ++k) swap32(&t[k]); if (sane(t)) need_swap = !need_swap; }
+            }
+            if (need_swap) for (int k = 0; k < 3; ++k) swap32(&q[k]);
+            mesh->vertices[v0 + i] = point(q[0], q[1], q[2]);
+        }
+    } else {
+        skip_comments(f);
+        for (int i = 0; i < nverts; ++i)
+            for (int j = 0; j < vert_len; ++j) {
+                float a, b, c; int ia, ib, ic;
+                if (j == vert_pos) { if (std::fscanf(f, "%f %f %f", &a, &b, &c) != 3) return fail("bad vertex"); mesh->vertices[v0 + i] = point(a, b, c); j += 2; }
+                else if (j == vert_norm) { if (std::fscanf(f, "%f %f %f", &a, &b, &c) != 3) return fail("bad normal"); j += 2; }
+                else if (j == vert_color && float_color) { if (std::fscanf(f, "%f %f %f", &a, &b, &c) != 3) return fail("bad colour"); j += 2; }
+                else if (j == vert_color) { if (std::fscanf(f, "%d %d %d", &ia, &ib, &ic) != 3) return fail("bad colour"); j += 2; }
+                else if (j == vert_conf) { if (std::fscanf(f, "%f", &a) != 1) return fail("bad confidence"); }
+                else if (std::fscanf(f, " %1023s", buf) != 1) return fail("truncated vertex data");
+            }
+    }
+    if (skip2) skip_data(skip2);
+    if (nfaces > 0) {
+        if (face_idx < 0) return fail("faces without a vertex index list");
+        std::vector<int> corners;
+        if (binary) {
+            const int face_skip = face_len - face_idx;
+            std::vector<unsigned char> rec(std::max(std::max(face_idx, face_skip), 4));
+            for (int i = 0; i < nfaces; ++i) {
+                if (face_idx > 0 && std::fread(rec.data(), face_idx, 1, f) != 1) return fail("truncated face data");
+                unsigned n = 3;
+                if (face_count >= 0) { if (face_idx - face_count == 4) { std::memcpy(&n, &rec[face_count], 4); if (need_swap) swap32(&n); } else n = rec[face_count]; }
+                if (n > 1000000u) return fail("implausible polygon size");
+                corners.resize(n);
+                if (n && std::fread(corners.data(), 4 * (size_t)n, 1, f) != 1) return fail("truncated face data");
+                if (need_swap) for (size_t k = 0; k < corners.size(); ++k) swap32(&corners[k]);
+                                for (size_t k = 0; k < corners.size(); ++k) if (corners[k] < 0 || corners[k] > (int)mesh->vertices.size()) return fail("face index outside the vertex list");
+                if (corners.size() == 4) for (size_t k = 0; k < 4; ++k) if (corners[k] >= (int)mesh->vertices.size()) return fail("face index outside the vertex list");
+                tess_polygon(mesh->vertices, corners, mesh->faces);
+                if (face_skip > 0 && std::fread(rec.data(), face_skip, 1, f) != 1) return fail("truncated face data");
+            }
+        } else {
+            skip_comments(f);
+            for (int i = 0; i < nfaces; ++i) {
+                corners.clear();
+                int count = 3;
+                for (int j = 0; j < face_len + count; ++j) {
+                    if (j >= face_idx && j < face_idx + count) { int v = 0; if (std::fscanf(f, " %d", &v) != 1) return fail("bad face index"); corners.push_back(v); }
+                    else if (j == face_count) { if (std::fscanf(f, " %d", &count) != 1) return fail("bad face count"); }
+                    else if (std::fscanf(f, " %1023s", buf) != 1) return fail("truncated face data");
+                }
+                if (corners.size() == 4) for (size_t k = 0; k < 4; ++k) if (corners[k] < 0 || corners[k] >= (int)mesh->vertices.size()) return fail("face index outside the vertex list");
+                tess_polygon(mesh->vertices, corners, mesh->faces);
+            }
+        }
+    }
+    return true;
+}
+
+// TriMesh::read_helper (:232-337): the file type from its first byte(s); afterwards check_ind_range (:1316-1347) -- indices that run 1..N (or k..k+N-1) are shifted to 0..N-1
+static inline bool read_mesh_file(const char *filename, TriMesh *mesh, std::string *why) {
+    FILE *f = std::fopen(filename, "rb");
+    if (!f) { if (why) *why = std::string("cannot open ") + filename; return false; }
+    bool ok = false;
+    const int c = std::fgetc(f);
+    if (c == 'p') { char b[4]; if (std::fgets(b, 4, f) && std::strncmp(b, "ly", 2) == 0) ok = read_ply_body(f, filename, mesh, why); else if (why) *why = std::string(filename) + ": unknown file type"; }
+    else if (c == '#') { char word[1025]; if (std::fscanf(f, "%1024s", word) != 1) word[0] = 0; ok = read_obj_body(f, filename, mesh, why); }
+    else if (c == 'v' || c == 'u' || c == 'f' || c == 'g' || c == 's' || c == 'o') { std::ungetc(c, f); ok = read_obj_body(f, filename, mesh, why); }
+    else if (why) *why = std::string(filename) + ": not a Wavefront OBJ or PLY file (the other formats of trimesh2's reader -- off, 3ds, stl, sm, vvd, ray -- are not carried)";
+    std::fclose(f);
+    if (ok && mesh->vertices.empty()) { ok = false; if (why) *why = std::string(filename) + ": no vertices"; }
+    if (!ok) { if (why && why->empty()) *why = std::string("error reading ") + filename; return false; }
+    if (!mesh->faces.empty()) {
+        int lo = mesh->faces[0][0], hi = lo;
+        for (size_t i = 0; i < mesh->faces.size(); ++i) for (int j = 0; j < 3; ++j) { lo = std::min(lo, mesh->faces[i][j]); hi = std::max(hi, mesh->faces[i][j]); }
+        const int nv = (int)mesh->vertices.size();
+        if (!(lo == 0 && hi == nv - 1)) {
+            if (hi - lo == nv - 1) { for (size_t i = 0; i < mesh->faces.size(); ++i) for (int j = 0; j < 3; ++j) mesh->faces[i][j] -= lo; }
+            else if (lo < 0 || hi >= nv) { if (why) *why = std::string(filename) + ": face indices outside the vertex list"; return false; }      // (trimesh2 goes on with them: undefined behaviour there)
+        }
+    }
+    return true;
 }
 
 } // namespace trimesh
@@ -885,7 +1060,7 @@ static inline std::shared_ptr<BaseObject> default_build_object(Component &obj) {
         if (!filename.size()) throw std::runtime_error("\n**TriangleMesh Error for obj " + obj.name + ": No file specified");
         std::shared_ptr<trimesh::TriMesh> tris(new trimesh::TriMesh());
         std::string why;
-        if (!trimesh::read_obj_file(filename.c_str(), tris.get(), &why)) {
+        if (!trimesh::read_mesh_file(filename.c_str(), tris.get(), &why)) {
             if (!obj.exists("force")) return std::shared_ptr<BaseObject>(new StaticShape(type, material));      // scenery in a format this loader does not read: parameters only, as before
             throw std::runtime_error("\n**TriangleMesh Error for obj " + obj.name + ": failed to load file " + filename + " (" + why + ")");
         }

@@ -131,7 +131,7 @@ public:
         if (!obj.exists("force")) return object; // static scenery
         std::shared_ptr<trimesh::TriMesh> mesh = object->get_TriMesh();
         if (!mesh) throw std::runtime_error("\n**ForceBuilder Error: object \"" + obj.name + "\" of type \"" + obj.type +
-                                            "\" has a Force, but this headless loader builds geometry only for tetmesh, plane, sphere, box, beam, cylinder and torus objects (not for mesh files or point clouds)");
+                                            "\" has a Force, but this headless loader builds geometry only for tetmesh, plane, sphere, box, beam, cylinder and torus objects and for OBJ / PLY meshes (not for other mesh files or point clouds)");
         double objMass = -1.0;
         if (obj.exists("mass")) objMass = obj.get("mass").as_double();
         if (objMass < 0.0) throw std::runtime_error("\n**Error: You must specify mass (kg) for object " + obj.name + ", e.g. <Mass type=\"double\" value=\"2\" />");

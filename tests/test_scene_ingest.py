@@ -30,6 +30,7 @@ SCENES = {
     "two_bodies": ("scenes/custom/two_bodies.xml", "none"),
     "uniform_nh": ("scenes/custom/uniform_nh.xml", "none"),
     "shapes": ("scenes/custom/shapes.xml", "none"),
+    "plymesh": ("scenes/custom/plymesh.xml", "none"),    # "trimesh" objects from PLY files: ascii with extra elements / properties, binary of both byte orders, 1-based indices
     "objmesh": ("scenes/custom/objmesh.xml", "none"),    # a "trimesh" object read from a Wavefront OBJ file (quads, a pentagon, v/vt/vn and relative indices, an unused vertex)      # sphere / box / beam / cylinder / torus tessellated like mclscene does, with forces on them
 }
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -144,19 +145,34 @@ def test_loader_errors(pkg, tmp_path):
                    '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
     assert r.returncode == 2 and "must specify mass" in r.stderr
-    # geometry this loader does not build (a point cloud, a mesh file that is not Wavefront OBJ) cannot carry a force; the primitives and OBJ meshes can
+    # geometry this loader does not build (a point cloud, a mesh file that is neither Wavefront OBJ nor PLY) cannot carry a force; the primitives, OBJ and PLY meshes can
     bad.write_text('<mclScene><Object name="s" type="pointcloud"><File value="x.ply"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
                    '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
     assert r.returncode == 2 and "builds geometry only for tetmesh, plane, sphere, box, beam, cylinder and torus" in r.stderr
     (tmp_path / "m.ply").write_text("ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
-    for fname, msg in (("missing.obj", "cannot open"), ("m.ply", "not a Wavefront OBJ file")):
+    (tmp_path / "m.off").write_text("OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    (tmp_path / "strips.ply").write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement tristrips 1\nproperty list int int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    for fname, msg in (("missing.obj", "cannot open"), ("m.off", "not a Wavefront OBJ or PLY file"), ("m.ply", "no float x y z vertices"), ("strips.ply", "triangle strips / range grids are not carried")):
         bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="%s"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
                        '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>' % fname)
         r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
         assert r.returncode == 2 and "failed to load file" in r.stderr and msg in r.stderr, r.stderr
+    # truncated / corrupt files are errors, never crashes: a binary PLY cut in the middle of its faces, one cut inside its vertices, an OBJ face naming vertex 99
+    src = open(os.path.join(GOLD, "scenes", "custom", "patch_le.ply"), "rb").read()
+    for cut, msg in ((len(src) - 40, "truncated face data"), (src.index(b"end_header") + 40, "truncated vertex data")):
+        (tmp_path / "cut.ply").write_bytes(src[:cut])
+        bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="cut.ply"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
+                       '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
+        r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
+        assert r.returncode == 2 and msg in r.stderr, r.stderr
+    (tmp_path / "far.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 99\n")
+    bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="far.obj"/><Mass value="1"/><Force value="f"/></Object></mclScene>'
+                   '<admmelastic><Force name="f" type="Spring"><stiffness value="1"/></Force></admmelastic>')
+    r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "face index outside" in r.stderr, r.stderr
     # ... while the same file as static scenery (no force) is accepted: parameters only
-    bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="m.ply"/></Object></mclScene><admmelastic></admmelastic>')
+    bad.write_text('<mclScene><Object name="s" type="trimesh"><File value="m.off"/></Object></mclScene><admmelastic></admmelastic>')
     r = subprocess.run([exe, str(bad), "none", str(dump), "-1"], capture_output=True, text=True)
     assert "failed to load file" not in r.stderr      # (a scene without any dynamic object: whatever the solver says about an empty system, the loader did not throw)
     # component without name/type
@@ -188,7 +204,7 @@ def run_scene(pkg, tmp_path, name, frames):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 1e-10), ("bunnyexpand", 1e-10), ("shapes", 1e-9), ("objmesh", 1e-9)])
+@pytest.mark.parametrize("name,tol", [("windyflag_nowind", 1e-9), ("windyflag", 1e-6), ("plinko", 1e-9), ("poordillo", 1e-10), ("bunnyexpand", 1e-10), ("shapes", 1e-9), ("objmesh", 1e-9), ("plymesh", 1e-9)])
 def test_shipped_scene_trajectories(pkg, tmp_path, name, tol):
     """The sample scenes, loaded from their XML by the headless SimContext and stepped on the GPU, against
     the reference's SimContext + System on the same files.  windyflag without wind / plinko contain no
