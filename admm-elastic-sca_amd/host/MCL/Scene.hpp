@@ -16,9 +16,9 @@
 // transform is applied in double and rounded back to float per coordinate, and the
 // same libstdc++ stream conversions parse and print the numbers.  What is NOT here:
 // rendering data (normals, tstrips, textures, materials, lights, cameras, BVH), trimesh2's
-// readers for mesh files other than Wavefront OBJ and PLY (off, 3ds, stl, sm ...) and point clouds: such
+// readers for mesh files other than Wavefront OBJ, PLY and OFF (3ds, stl, sm ...) and point clouds: such
 // objects are accepted as static scenery (their parameters are kept); giving one a <Force> is an error.
-//   trimesh: <File> .obj / .ply                  (trimesh2 libsrc/TriMesh_io.cc:232-337,342-556,736-788,870-1150,1243-1407) -- round 5
+//   trimesh: <File> .obj / .ply / .off           (trimesh2 libsrc/TriMesh_io.cc:232-337,342-556,736-806,870-1150,1243-1407) -- round 5
 //   sphere / box / beam / cylinder / torus       (mclscene DefaultBuilders.hpp:83-256 over trimesh2 TriMeshBuilder.h:220-556,
 //                                                 libsrc/remove.cc) -- round 5: tessellated like the reference does, forces attach
 //
@@ -617,6 +617,30 @@ static inline bool read_ply_body(FILE *f, const char *filename, TriMesh *mesh, s
     return true;
 }
 
+// OFF (read_off :792-806): counts line, `x y z` per vertex, `n i0 .. i(n-1)` per face, the rest of a face's line (colours) ignored
+static inline bool read_off_body(FILE *f, const char *filename, TriMesh *mesh, std::string *why) {
+    auto fail = [&](const char *msg) { if (why) *why = std::string(filename) + ": " + msg; return false; };
+    char buf[1024];
+    skip_comments(f);
+    if (!std::fgets(buf, 1024, f)) return fail("truncated header");
+    int nverts = 0, nfaces = 0, unused = 0;
+    if (std::sscanf(buf, "%d %d %d", &nverts, &nfaces, &unused) < 2 || nverts <= 0 || nfaces < 0) return fail("bad OFF counts");
+    skip_comments(f);
+    for (int i = 0; i < nverts; ++i) { float a, b, c; if (std::fscanf(f, "%f %f %f", &a, &b, &c) != 3) return fail("bad vertex"); mesh->vertices.push_back(point(a, b, c)); }
+    if (nfaces) skip_comments(f);
+    std::vector<int> corners;
+    for (int i = 0; i < nfaces; ++i) {
+        int count = 3;
+        if (std::fscanf(f, " %d", &count) != 1 || count < 0 || count > 1000000) return fail("bad face count");
+        corners.clear();
+        for (int j = 0; j < count; ++j) { int v = 0; if (std::fscanf(f, " %d", &v) != 1) return fail("bad face index"); corners.push_back(v); }
+        if (corners.size() == 4) for (size_t k = 0; k < 4; ++k) if (corners[k] < 0 || corners[k] >= (int)mesh->vertices.size()) return fail("face index outside the vertex list");
+        tess_polygon(mesh->vertices, corners, mesh->faces);
+        for (;;) { const int c = std::fgetc(f); if (c == EOF || c == '\n') break; }
+    }
+    return true;
+}
+
 // TriMesh::read_helper (:232-337): the file type from its first byte(s); afterwards check_ind_range (:1316-1347) -- indices that run 1..N (or k..k+N-1) are shifted to 0..N-1
 static inline bool read_mesh_file(const char *filename, TriMesh *mesh, std::string *why) {
     FILE *f = std::fopen(filename, "rb");
@@ -626,7 +650,8 @@ static inline bool read_mesh_file(const char *filename, TriMesh *mesh, std::stri
     if (c == 'p') { char b[4]; if (std::fgets(b, 4, f) && std::strncmp(b, "ly", 2) == 0) ok = read_ply_body(f, filename, mesh, why); else if (why) *why = std::string(filename) + ": unknown file type"; }
     else if (c == '#') { char word[1025]; if (std::fscanf(f, "%1024s", word) != 1) word[0] = 0; ok = read_obj_body(f, filename, mesh, why); }
     else if (c == 'v' || c == 'u' || c == 'f' || c == 'g' || c == 's' || c == 'o') { std::ungetc(c, f); ok = read_obj_body(f, filename, mesh, why); }
-    else if (why) *why = std::string(filename) + ": not a Wavefront OBJ or PLY file (the other formats of trimesh2's reader -- off, 3ds, stl, sm, vvd, ray -- are not carried)";
+    else if (c == 'O') { char b[3]; if (std::fgets(b, 3, f) && std::strncmp(b, "FF", 2) == 0) ok = read_off_body(f, filename, mesh, why); else if (why) *why = std::string(filename) + ": unknown file type"; }
+    else if (why) *why = std::string(filename) + ": not a Wavefront OBJ, PLY or OFF file (the other formats of trimesh2's reader -- 3ds, stl, sm, vvd, ray -- are not carried)";
     std::fclose(f);
     if (ok && mesh->vertices.empty()) { ok = false; if (why) *why = std::string(filename) + ": no vertices"; }
     if (!ok) { if (why && why->empty()) *why = std::string("error reading ") + filename; return false; }

@@ -35,9 +35,9 @@ SCENES = {
     "uniform_nh": ("scenes/custom/uniform_nh.xml", "none", 0),
     "shapes": ("scenes/custom/shapes.xml", "none", 2),      # round 5: sphere / box / beam / cylinder / torus as dynamic objects
     "objmesh": ("scenes/custom/objmesh.xml", "none", 2),    # round 5: a "trimesh" object from a Wavefront OBJ file
-    "plymesh": ("scenes/custom/plymesh.xml", "none", 2),    # round 5: "trimesh" objects from PLY files (ascii, binary little / big endian)
+    "plymesh": ("scenes/custom/plymesh.xml", "none", 2),    # round 5: "trimesh" objects from PLY files (ascii, binary little / big endian) and an OFF file
 }
-DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b", "ball", "crate", "girder", "can", "ring", "patch", "pa", "ple", "pbe")
+DYNAMIC = ("bunny", "dillo", "horse", "cloth1", "sheet", "a", "b", "ball", "crate", "girder", "can", "ring", "patch", "pa", "ple", "pbe", "poff")
 
 
 def child(name):
