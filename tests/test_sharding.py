@@ -346,6 +346,49 @@ def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(8, "subtree"), (4, "contiguous")])
+def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
+    """The headline workload as the multi-GPU runs cut it -- the 1,001,472-tet Neo-Hookean bar in 8 subtree shards (4 contiguous shards) -- on ONE
+    GPU (one context and host thread per rank, the hook sums the ranks' buffers): after one frame of 20 iterations every rank holds the same bits,
+    and they agree with the COMPILED REFERENCE's frame (tests/golden/traj_bar_1M.npz) within the bound every trajectory fixture uses, 20 x the
+    reference's own sensitivity to a 1-ulp perturbation of its start -- the sharded sums meet in another order than the single-GPU run's, the
+    local steps are bit-identical.  The partition is exact and the exchange is the small one (subtree: top rows only)."""
+    from conftest import golden
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "traj_bar_1M.npz")):
+        pytest.skip("full-size fixture not generated")
+    g = golden("traj_bar_1M.npz")
+    dims = [int(v) for v in g["dims"]]
+    shards = [pkg.make_bar_system(*dims, rank=r, world=world, shard_mode=mode) for r in range(world)]
+    hooks = _thread_allreduce_hooks(world)
+    for r, s in enumerate(shards):
+        s.set_allreduce(hooks[r]); s.keep_z(False); s.initialize()
+    infos = [s.info() for s in shards]
+    assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"] and infos[0]["n_nodes"] == int(g["n_nodes"])
+    if mode == "subtree":
+        assert sum(i["nodes_own"] for i in infos) + infos[0]["nodes_top"] == infos[0]["n_nodes"]
+        assert 8 * infos[0]["comm_doubles_iter"] < 1 << 20                   # well under a megabyte per iteration (the whole RHS is 4.29 MB)
+    out = [None] * world
+    errs = []
+
+    def run(r):
+        try:
+            shards[r].step(int(g["iters"]))
+            out[r] = shards[r].m_x
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(timeout=600) for t in th]
+    assert not errs and all(o is not None for o in out), errs
+    for r in range(1, world):
+        assert np.array_equal(out[r], out[0]), r
+    x = out[0].reshape(-1, 3)
+    bound = max(1e-9, 20.0 * float(g["ulp_sensitivity"]))
+    err = np.abs(x[::int(g["stride"])] - g["x_sample"]).max()
+    assert err < bound, (err, bound)
+    assert abs(np.abs(x).sum() - float(g["sum_abs"])) < bound * x.size
+
+
+@pytest.mark.gpu
 def test_two_shards_on_one_gpu(pkg):
     import torch
     dims = (5, 4, 11)
