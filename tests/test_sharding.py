@@ -389,6 +389,44 @@ def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
 
 
 @pytest.mark.gpu
+def test_full_size_mixed_scene_in_8_shards_vs_compiled_reference(pkg):
+    """BASELINE.json configs[4] as it is meant to run -- 498,888 NH + StVK tets, 99,856 cloth triangles, 149k hinges, anchors on "8 GPUs" -- as 8 subtree
+    shards on ONE GPU: every force kernel of the scene under sharding (one launch per rank for its whole local step), two bodies = two elimination
+    trees whose tops are replicated; all ranks bitwise equal after one 20-iteration frame and inside the compiled reference's envelope
+    (tests/golden/traj_mixed_full.npz)."""
+    from conftest import golden
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "traj_mixed_full.npz")):
+        pytest.skip("full-size fixture not generated")
+    g = golden("traj_mixed_full.npz")
+    world = 8
+    shards = [pkg.make_mixed_system(*[int(v) for v in g["bar_dims"]], *[int(v) for v in g["cloth"]], rank=r, world=world, shard_mode="subtree")[0] for r in range(world)]
+    hooks = _thread_allreduce_hooks(world)
+    for r, s in enumerate(shards):
+        s.set_allreduce(hooks[r]); s.keep_z(False); s.initialize()
+    infos = [s.info() for s in shards]
+    assert infos[0]["n_nodes"] == int(g["n_nodes"]) and sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"]
+    out = [None] * world
+    errs = []
+
+    def run(r):
+        try:
+            shards[r].step(int(g["iters"]))
+            out[r] = shards[r].m_x
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(timeout=600) for t in th]
+    assert not errs and all(o is not None for o in out), errs
+    for r in range(1, world):
+        assert np.array_equal(out[r], out[0]), r
+    x = out[0].reshape(-1, 3)
+    bound = max(1e-9, 20.0 * float(g["ulp_sensitivity"]))
+    err = np.abs(x[::int(g["stride"])] - g["x_sample"]).max()
+    assert err < bound, (err, bound)
+    assert abs(np.abs(x).sum() - float(g["sum_abs"])) < bound * x.size
+
+
+@pytest.mark.gpu
 def test_two_shards_on_one_gpu(pkg):
     import torch
     dims = (5, 4, 11)
