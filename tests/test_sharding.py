@@ -568,11 +568,11 @@ def test_bench_watchdog_ends_a_stalled_process():
     a plain exit from a daemon thread, no re-exec; a process that keeps beating, or that stopped the watchdog, is left alone."""
     code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
             "w = bench.Watchdog(3, 8, limit_s=30.0, poll_s=0.05)\n"
-            "for i in range(5): w.beat('frame %%d' %% i, 0.4); time.sleep(0.1)\n"
+            "for i in range(5): w.beat('frame %%d' %% i, 20.0); time.sleep(0.05)\n"      # (generous while it beats: a loaded build container must not trip it)
             "mode = sys.argv[1]\n"
             "if mode == 'stop': w.stop()\n"
-            "w.beat('timed frame 7: waiting for its events') if mode != 'stop' else None\n"
-            "time.sleep(1.5); print('survived')\n") % ROOT
+            "w.beat('timed frame 7: waiting for its events', 0.3) if mode != 'stop' else None\n"
+            "time.sleep(3.0); print('survived')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code, "hang"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and "survived" not in r.stdout
     assert "rank 3 of 8" in r.stderr and "timed frame 7: waiting for its events" in r.stderr and "exiting with code 3" in r.stderr
