@@ -461,6 +461,8 @@ def main():
     sync_all()
     # per-frame limit of the timed region: 100 x the warm-up frame (it holds the first collective's lazy set-up and the graph capture)
     frame_limit = max(float(os.environ.get("ADMM_BENCH_FRAME_TIMEOUT_MIN", "30")), 100.0 * (time.perf_counter() - t_w) / max(a.warmup, 1))
+    if os.environ.get("ADMM_BENCH_FRAME_TIMEOUT_MAX"):      # (tests: a fixed upper end, whatever the warm-up frame of a cold box took)
+        frame_limit = min(frame_limit, float(os.environ["ADMM_BENCH_FRAME_TIMEOUT_MAX"]))
     # HIP events on the solver's stream around the phases of every TIMING_STRIDE-th ADMM iteration of the timed region (a frame's events
     # are read back after the NEXT frame has been queued); the other iterations run event-free.  An event is a barrier packet (~5 us of
     # lost launch overlap each): around every iteration they cost 3.7 % at one GPU, around every 10th 0.7 % (tools/probe/event_overhead.py).

@@ -586,7 +586,7 @@ def test_bench_two_ranks_a_hung_collective_exits_nonzero():
     end the ranks within the per-frame limit, bench.py relays a non-zero code, no JSON line, and stderr says which rank stalled where."""
     import time
     args = ["--steps", "2", "--warmup", "1", "--dims", "8", "8", "40", "--no-cpu-baseline"]
-    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5",
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5", ADMM_BENCH_FRAME_TIMEOUT_MAX="10",
                ADMM_BENCH_TEST_HANG_RANK="1", ADMM_BENCH_TEST_HANG_AFTER="30")      # warm-up frame: 20 calls + the frame's x; then the 10th iteration of timed frame 0
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     t = time.time()
