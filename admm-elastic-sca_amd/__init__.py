@@ -43,7 +43,9 @@ class Info(C.Structure):
                [(n, C.c_double) for n in ("t_order_s", "t_symbolic_s", "t_numeric_s", "t_upload_s")] + \
                [(n, C.c_int32) for n in ("rank", "world", "device_id", "host_threads", "dense_solve", "device_factor")] + \
                [(n, C.c_int64) for n in ("rhs_slots", "sweep_entries_own", "sweep_entries_top", "sweep_entries_top_bwd", "nodes_own", "nodes_top",
-                                         "comm_doubles_iter", "comm_doubles_frame")]
+                                         "comm_doubles_iter", "comm_doubles_frame", "factor_doubles_resident", "front_doubles",
+                                         "factor_exchange_doubles")] + \
+               [(n, C.c_int32) for n in ("factor_local", "reserved_")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -90,6 +92,7 @@ def lib():
         L.admm_hip_destroy.restype = None
         L.admm_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.admm_hip_set_shard_mode.argtypes = [C.c_void_p, C.c_int]
+        L.admm_hip_set_factor_local.argtypes = [C.c_void_p, C.c_int]
         L.admm_hip_debug_node_owner.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.admm_hip_local_elements.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]
         L.admm_hip_enable_residuals.argtypes = [C.c_void_p, C.c_int]
@@ -407,6 +410,10 @@ class System:
     def set_shard_mode(self, mode):
         self._chk(self.L.admm_hip_set_shard_mode(self.h, SHARD[mode] if isinstance(mode, str) else int(mode)))
 
+    def set_factor_local(self, on):
+        """Rank-local factorization under subtree sharding (default on): initialize() / recompute_weights() are then collective calls."""
+        self._chk(self.L.admm_hip_set_factor_local(self.h, int(bool(on))))
+
     def read_local(self, batch):
         kind, _ = self.batches[batch]
         if kind == KIND_GENERIC:     # u, z of this rank's user forces, element after element
@@ -498,6 +505,29 @@ class System:
         t = Timing()
         self._chk(self.L.admm_hip_get_timing_previous(self.h, C.byref(t)))
         return t.as_dict()
+
+
+def initialize_together(systems, timeout=3600.0):
+    """initialize() of several ranks' contexts living in ONE process (tests, tools/ranks_one_gpu.py), each from its own thread:
+    under rank-local factorization (subtree shards, the default) admm_hip_finalize is a collective call -- the ranks meet in the
+    all-reduce of the subtree roots' update matrices -- exactly like System::initialize() of N real processes."""
+    import threading
+    errs = []
+
+    def run(s):
+        try:
+            s.initialize()
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(s,), daemon=True) for s in systems]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    if errs:
+        raise errs[0]
+    if any(t.is_alive() for t in th):
+        raise AdmmHipError("initialize_together: a rank is still inside initialize() after %g s" % timeout)
 
 
 def make_bar_system(nx, ny, nz, kind=KIND["TET_NH"], mu=1e5, lam=1e5, max_iter=5, density=1000.0, h=0.05, dt=0.04,

@@ -137,6 +137,11 @@ struct admm_hip_ctx {
     int shard_mode = 0;                       // 0: contiguous element ranges + replicated solve, 1: subtrees
     std::vector<int> sn_owner, node_owner;    // -1 = top (replicated); node_owner in factor order
     std::vector<LevelDev> levels_top;         // sweep items of the top supernodes (levels = this rank's own ones)
+    // rank-local factorization (admm_hip_set_factor_local): under subtree sharding a rank assembles, factors and keeps only its own subtrees and
+    // the replicated top; the subtree roots' update matrices meet in ONE all-reduce per factorization (dev_factorize.inc).  The device's panel
+    // layout is then a compact one over those supernodes (dev_panel_off; -1 = not resident) -- Factor::panel_off stays the host layout.
+    bool factor_local = true, factor_local_on = false;      // wanted / in effect (set by plan_device_panels at finalize)
+    std::vector<int64_t> dev_panel_off, dev_root_inv_off; int64_t dev_panels_size = 0;
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;
     int merge_small = 0;                          // dissection regions of at most that many nodes become four-way tree nodes (ADMM_HIP_MERGE_SMALL)
@@ -251,6 +256,7 @@ void partition_subtrees(admm_hip_ctx *ctx);                                     
 void assign_elements(admm_hip_ctx *ctx);
 void top_needs(const admm_hip_ctx *ctx, std::vector<std::vector<char> > &need, std::vector<int> &provider);
 void shard_accounting(admm_hip_ctx *ctx);
+void plan_device_panels(admm_hip_ctx *ctx);
 void subtree_owners(const admm_host::Factor &F, int parts, std::vector<int> &owner, std::vector<double> &load, int &n_top, size_t &n_sub);
 void xcd_order(std::vector<admm_dev::SweepItem> &items, int group, int min_supernodes);
 

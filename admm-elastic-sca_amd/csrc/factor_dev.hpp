@@ -197,7 +197,11 @@ __global__ void assemble_kernel(int64_t nnz, const int64_t *__restrict__ dst, co
 
 // extend-add of one child's update matrix U (rc x rc lower, at `U`, leading dimension fc) into its parent's front (leading dimension fp):
 // P[rel[a] + fp rel[b]] += U[a + fc b], a >= b.  blockIdx.y = task, blockIdx.x = group of 8 columns.
-struct ExtendTask { const double *U; double *P; const int *rel; int rc, fc, fp, pad; };
+// packed != 0: U is the lower triangle stored column after column without gaps (column b = rows b .. rc - 1) -- the form in which the
+// update matrices of the subtree roots travel between the ranks (rank-local factorization, pack_lower_kernel).
+struct ExtendTask { const double *U; double *P; const int *rel; int rc, fc, fp, packed; };
+
+__device__ __forceinline__ size_t packed_col(int rc, int b) { return (size_t)b * rc - (size_t)b * (b - 1) / 2; }      // first entry of column b
 
 __global__ __launch_bounds__(256) void extend_add_kernel(const ExtendTask *__restrict__ tasks) {
     const ExtendTask T = tasks[blockIdx.y];
@@ -205,7 +209,22 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const ExtendTask *__res
     if (b0 >= T.rc) return;
     for (int b = b0; b < min(b0 + 8, T.rc); ++b) {
         const size_t pc = (size_t)T.fp * T.rel[b];
-        for (int a = b + threadIdx.x; a < T.rc; a += 256) T.P[T.rel[a] + pc] += T.U[a + (size_t)T.fc * b];
+        const double *Ucol = T.packed ? T.U + packed_col(T.rc, b) - b : T.U + (size_t)T.fc * b;
+        for (int a = b + threadIdx.x; a < T.rc; a += 256) T.P[T.rel[a] + pc] += Ucol[a];
+    }
+}
+
+// out (packed lower triangle, see above) = the update matrix U (rc x rc lower, leading dimension fc) of a factored front
+struct PackTask { const double *U; double *out; int rc, fc; };
+
+__global__ __launch_bounds__(256) void pack_lower_kernel(const PackTask *__restrict__ tasks) {
+    const PackTask T = tasks[blockIdx.y];
+    const int b0 = blockIdx.x * 8;
+    if (b0 >= T.rc) return;
+    for (int b = b0; b < min(b0 + 8, T.rc); ++b) {
+        const double *Ucol = T.U + (size_t)T.fc * b;
+        double *o = T.out + packed_col(T.rc, b) - b;
+        for (int a = b + threadIdx.x; a < T.rc; a += 256) o[a] = Ucol[a];
     }
 }
 

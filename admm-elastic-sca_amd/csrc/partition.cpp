@@ -145,6 +145,37 @@ void shard_accounting(admm_hip_ctx *ctx) {
     I.comm_doubles_frame = 3 * (int64_t)F.n;               // the full x, once per frame (shard_sync_x)
 }
 
+// The device's panel layout (after partition_subtrees): which supernodes' panels live on THIS rank's device and where.  One rank,
+// contiguous shards, factor_local off or no transport installed yet: all of them, in the host layout.  Rank-local (subtree shards): the
+// rank's own supernodes and the replicated top, packed in supernode order, the resident roots' explicit inverses behind them.
+void plan_device_panels(admm_hip_ctx *ctx) {
+    const Factor &F = ctx->F;
+    const int ns = (int)F.sn.size();
+    ctx->factor_local_on = ctx->factor_local && ctx->shard_mode == 1 && ctx->world > 1 && ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce);
+    ctx->dev_panel_off.assign(ns, -1); ctx->dev_root_inv_off.assign(ns, -1);
+    if (!ctx->factor_local_on) {
+        for (int s = 0; s < ns; ++s) { ctx->dev_panel_off[s] = F.sn[s].panel_off; ctx->dev_root_inv_off[s] = F.sn[s].root_inv_off; }
+        ctx->dev_panels_size = F.panels_size;
+    } else {
+        int64_t size = 0;
+        auto resident = [&](int s) { return ctx->sn_owner[s] == ctx->rank || ctx->sn_owner[s] < 0; };
+        for (int s = 0; s < ns; ++s) if (resident(s)) { ctx->dev_panel_off[s] = size; size += (int64_t)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols; }
+        for (int s = 0; s < ns; ++s) {
+            if (!resident(s) || F.sn[s].root_inv_off < 0) continue;
+            const int64_t off = (size + 15) & ~(int64_t)15;
+            ctx->dev_root_inv_off[s] = off;
+            size = off + (int64_t)root_inv_ld(F.sn[s].ncols) * F.sn[s].ncols;
+        }
+        ctx->dev_panels_size = size;
+    }
+    ctx->info.factor_local = ctx->factor_local_on ? 1 : 0;
+    ctx->info.factor_doubles_resident = ctx->dev_panels_size;
+    ctx->info.front_doubles = 0; ctx->info.factor_exchange_doubles = 0;
+    if (getenv("ADMM_HIP_VERBOSE") && ctx->world > 1)
+        fprintf(stderr, "admm_hip: rank %d: %s factorization, %.3f GB of the factor's %.3f GB resident\n", ctx->rank, ctx->factor_local_on ? "rank-local" : "whole (replicated)",
+                ctx->dev_panels_size * 8e-9, F.panels_size * 8e-9);
+}
+
 // this rank's elements of every batch
 void assign_elements(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;

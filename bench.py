@@ -396,6 +396,8 @@ def main():
     else:
         s = pkg.make_bar_system(nx, ny, nz, device_id=local_rank, rank=int(os.environ.get("ADMM_BENCH_FAKE_RANK", "0")) if fake_world > 1 else rank,
                                 world=fake_world if fake_world > 1 else world, stream=stream.cuda_stream, shard_mode=a.shard)
+    if fake_world > 1:
+        s.set_factor_local(False)      # ONE rank's share with identity "sums": the top of the tree can only be factored whole
     if fake_world > 1 and not fake_dist:
         s.set_allreduce(lambda ptr, count, strm: 0)
     if world > 1 or fake_dist:

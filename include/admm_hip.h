@@ -295,8 +295,23 @@ typedef struct admm_hip_info {
     int64_t nodes_own, nodes_top;   /* nodes of the own subtrees / of the replicated top                                     */
     int64_t comm_doubles_iter;      /* doubles summed across the ranks per ADMM iteration (one collective)                   */
     int64_t comm_doubles_frame;     /* additionally once per frame (subtree shards: the full x before the velocity update)   */
+    /* rank-local factorization (subtree shards, admm_hip_set_factor_local): what THIS rank factors and keeps on its device   */
+    int64_t factor_doubles_resident; /* doubles of factor panels (+ root inverses) resident on this rank's device; one rank / contiguous shards /
+                                        factor_local = 0: the whole factor = panel_bytes / 8                                     */
+    int64_t front_doubles;           /* doubles of frontal matrices this rank's numeric factorization held at once (0: factored on the host) */
+    int64_t factor_exchange_doubles; /* doubles summed across the ranks ONCE per factorization (the subtree roots' update matrices) */
+    int32_t factor_local;            /* 1: this rank factored only its own subtrees + the replicated top                          */
+    int32_t reserved_;
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
+/* Rank-local factorization (default on; ADMM_HIP_FACTOR_LOCAL=0 / 1 overrides).  Under subtree sharding with world > 1 a rank sweeps
+ * only its own subtrees and the replicated top of the elimination tree, so that is all it assembles, factors and keeps on its device:
+ * System::initialize's ONE solver.compute(A) (System.cpp:138-140) is split N ways instead of repeated N times.  The update matrices
+ * of the subtree roots meet in ONE all-reduce through the installed transport (owner's values + zeros elsewhere), after which every
+ * rank factors the top from the same bits.  That makes admm_hip_finalize and admm_hip_recompute_weights COLLECTIVE calls in this
+ * mode: the transport must be installed before finalize and every rank must be inside the call at the same time.  With no transport
+ * installed at finalize (or on = 0, or contiguous shards) every rank factors the whole matrix as before.  Before finalize only.  */
+int admm_hip_set_factor_local(admm_hip_ctx *ctx, int on);
 
 /* per-phase device timing of the last admm_hip_step (HIP events on the
  * context's stream; enabled with admm_hip_enable_timing).  ms per frame.      */

@@ -47,6 +47,19 @@ def have_ref():
     return os.path.exists(lib)
 
 
+def deformed_start(x0):
+    """A smooth, LARGE deformation of a bar's rest positions built from + and * only (no transcendental, no division: the same
+    bits on every host and every numpy build): shear, bending and twist-like terms that put the deformation gradients 5-20 %
+    away from the identity.  The start of the one-iteration full-size fixture (tests/golden/traj_bar_1M_one_iter.npz): with it
+    the single local step of that frame is a real Neo-Hookean prox for every tet instead of the identity."""
+    p = np.asarray(x0, dtype=np.float64).reshape(-1, 3)
+    q = p.copy()
+    q[:, 0] = p[:, 0] + 0.02 * (p[:, 1] * p[:, 2])
+    q[:, 1] = p[:, 1] - 0.004 * (p[:, 2] * p[:, 2])
+    q[:, 2] = p[:, 2] + 0.03 * (p[:, 0] * p[:, 1])
+    return q.ravel()
+
+
 def solve_rhs(seed, x0, m3):
     """The three right-hand sides of the direct solve fixtures (tests/golden/solve_*.npz; 3n doubles each, node-major like
     System::m_x): white noise, an M x_bar-like smooth vector (mass x displaced positions, what System.cpp:61 feeds the solver),

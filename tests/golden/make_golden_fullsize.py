@@ -9,7 +9,16 @@
 
   traj_mixed_full.npz   the same for BASELINE.json configs[4] at full size (498,888 NH + StVK tets, 99,856 triangles, 149k hinges).
 
+  traj_bar_1M_one_iter.npz   (round 6) the same bar after a frame of ONE ADMM iteration from a strongly deformed start
+                    (checkers.deformed_start: + and * only, so the same bits everywhere) -- the tight check at the headline
+                    size: only the rounding of one global solve separates implementations there, and u / z / warm-start state
+                    of that iteration come from the local step on the bit-identical start, so they must match bit for bit.
+                    x at every 8th node, u / z / state of every 64th tet and of every anchor, sums over everything; plus
+                    the reference's own solver.solve(b) for the three right-hand sides of checkers.solve_rhs at this size
+                    (x at every 8th node) on the SAME factor object (one 23-minute initialize serves both).
+
   python tests/golden/make_golden_fullsize.py          (writes tests/golden/traj_bar_1M.npz)
+  python tests/golden/make_golden_fullsize.py one_iter (writes tests/golden/traj_bar_1M_one_iter.npz)
   python tests/golden/make_golden_fullsize.py mixed    (writes tests/golden/traj_mixed_full.npz)
 """
 import os
@@ -72,9 +81,52 @@ def main_mixed():
     print("mixed: 1-ulp sensitivity after one frame: %.3e (max |x| %.3f)" % (sens, np.abs(xa).max()))
 
 
+def main_one_iter():
+    from checkers import deformed_start, solve_rhs
+    TSTRIDE = 64
+    t0 = time.time()
+    r = bar_system(Ref, KIND["TET_NH"], DIMS, 1e5, 1e5, 1)
+    t1 = time.time()
+    print("initialize %.0f s" % (t1 - t0), flush=True)
+    x0 = r.x.copy(); m3 = r.masses.copy()
+    # the reference's own solver.solve(b) first (it does not touch the simulation state)
+    B = solve_rhs(11, x0, m3)
+    SX = []
+    for b in B:
+        SX.append(r.solve(b).reshape(-1, 3)[::STRIDE].copy())
+    t2 = time.time()
+    print("3 solves %.0f s" % (t2 - t1), flush=True)
+    r.x = deformed_start(x0)
+    r.step()
+    t3 = time.time()
+    print("one-iteration frame %.0f s" % (t3 - t2), flush=True)
+    x = r.x.reshape(-1, 3); v = r.v.reshape(-1, 3)
+    u = r.u; z = r.z
+    nt = 6 * DIMS[0] * DIMS[1] * DIMS[2]
+    na = (DIMS[0] + 1) * (DIMS[1] + 1)
+    gi = r.global_idx()
+    assert gi[0] == 0 and gi[1] == 36 and gi[nt] == 36 * nt and u.size == 36 * nt + 3 * na       # the reference's 36 rows per tet, 9 of them real
+    ut = u[:36 * nt].reshape(nt, 36); zt = z[:36 * nt].reshape(nt, 36)
+    assert not ut[:, 9:].any() and not zt[:, 9:].any()
+    ua = u[36 * nt:].reshape(na, 3); za = z[36 * nt:].reshape(na, 3)
+    tets = np.arange(0, nt, TSTRIDE)
+    st = np.zeros((tets.size, 4)); it = np.zeros(tets.size, np.int32)
+    for k, e in enumerate(tets):
+        st[k], it[k] = r.hyper_state(int(e))
+    np.savez_compressed(os.path.join(HERE, "traj_bar_1M_one_iter.npz"), dims=np.array(DIMS), stride=STRIDE, tet_stride=TSTRIDE, iters=1, dt=0.04, mu=1e5, lam=1e5, max_iter=5,
+                        n_nodes=x.shape[0], x_sample=x[::STRIDE], v_sample=v[::STRIDE], sum_abs=float(np.abs(x).sum()), sum_sq=float((x * x).sum()),
+                        u_tets=ut[tets, :9], z_tets=zt[tets, :9], state_tets=st, n_iters_tets=it, u_anchors=ua, z_anchors=za,
+                        u_sum_abs=float(np.abs(ut[:, :9]).sum()), u_sum_sq=float((ut[:, :9] ** 2).sum()), z_sum_abs=float(np.abs(zt[:, :9]).sum()), z_sum_sq=float((zt[:, :9] ** 2).sum()),
+                        solve_seed=11, solve_x_sample=np.array(SX), solve_x_max=np.array([np.abs(s).max() for s in SX]),
+                        ref_initialize_s=t1 - t0, ref_solve_s=(t2 - t1) / 3, ref_frame_s=t3 - t2)
+    print("written; max |u| %.3e, L-BFGS iteration histogram of the sample %s" % (np.abs(ut).max(), np.bincount(it)))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "mixed":
         return main_mixed()
+    if len(sys.argv) > 1 and sys.argv[1] == "one_iter":
+        return main_one_iter()
     xa, t_init, t_step = run(0.0)
     np.savez_compressed(os.path.join(HERE, "traj_bar_1M_partial.npz"), x=xa[::STRIDE])          # keep something if the second run dies
     xb, _, _ = run(2e-16)

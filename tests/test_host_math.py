@@ -138,8 +138,8 @@ def test_linesearch_case_coverage(hm):
     """The More-Thuente step selection is written as one expression tree on selected operands (local_math.hpp mt_cstep);
     the bit-exact projections above only pin it if they reach every case, with and without a bracket, and the stage-1
     modified function."""
-    test_project_hyper(hm, "TET_NH", [50, 80, 20], 10)
-    test_project_hyper(hm, "TET_STVK", [3e3, 1e3, 12], 10)
+    for name, params, M in (("TET_NH", [1e5, 1e5, 5], 5), ("TET_NH", [50, 80, 20], 10), ("TET_NH", [1e3, 2e3, 3], 5), ("TET_STVK", [100, 100, 5], 5), ("TET_STVK", [3e3, 1e3, 12], 10)):
+        test_project_hyper(hm, name, params, M)      # (all of them here: the counters must not depend on which tests ran before, e.g. under pytest -k / -n)
     st = (C.c_long * 9)()
     hm.hm_cstep_stats(st)
     st = list(st)

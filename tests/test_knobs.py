@@ -179,7 +179,8 @@ def test_sharding_knobs(pkg, monkeypatch, knob, value):
     shards = [_bar(pkg, "TET_LINEAR", [4000.0], dims=dims, rank=r, world=world, mode=caller_mode) for r in range(world)]
     hooks = _hooks(world)
     for r, s in enumerate(shards):
-        s.set_allreduce(hooks[r]); s.initialize()
+        s.set_allreduce(hooks[r])
+    pkg.initialize_together(shards)
     out = [None] * world
 
     def run(r):

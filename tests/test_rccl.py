@@ -86,6 +86,7 @@ res = {}
 for variant in ("hook", "rccl-eager", "rccl-graph"):
     os.environ["ADMM_HIP_GRAPH_COMM"] = "1" if variant == "rccl-graph" else "0"
     s = pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=rank, world=world, shard_mode=mode)
+    s.set_factor_local(False)      # one rank's share behind a 1-rank communicator: nobody delivers the other subtrees' update matrices
     calls = [0]
     if variant == "hook":
         def noop(ptr, count, strm):

@@ -273,7 +273,7 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
         for r, s in enumerate(shards):
             s.set_shard_mode(mode)
             s.set_allreduce(hooks[r])
-            s.initialize()
+        pkg.initialize_together(shards)          # (collective under rank-local factorization: one thread per rank)
         assert sum(s.info()["n_elems_local"] for s in shards) == ref.info()["n_elems_total"]
         b = np.random.default_rng(2).normal(size=3 * ref.n_nodes)
         xref = ref.solve_only(b)
@@ -309,7 +309,8 @@ def test_backward_over_the_top_only_where_a_rank_reads_it(pkg, monkeypatch):
             shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world) for r in range(world)]
             hooks = _thread_allreduce_hooks(world)
             for r, s in enumerate(shards):
-                s.set_shard_mode("subtree"); s.set_allreduce(hooks[r]); s.initialize()
+                s.set_shard_mode("subtree"); s.set_allreduce(hooks[r])
+            pkg.initialize_together(shards)
             res[knob] = _run_sharded(shards, 2, 10, b)
         for r in range(world):
             assert np.abs(res["0"][r][0] - xref).max() < 1e-10 * np.abs(xref).max(), (world, r, "solve vs one rank")
@@ -331,7 +332,8 @@ def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
     shards = [pkg.make_bar_system(*dims, rank=r, world=world) for r in range(world)]
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
-        s.set_shard_mode("subtree"); s.set_allreduce(hooks[r]); s.initialize()
+        s.set_shard_mode("subtree"); s.set_allreduce(hooks[r])
+    pkg.initialize_together(shards)
     assert shards[0].info()["n_levels"] < ref.info()["n_levels"] or shards[0].info()["n_levels"] <= 6      # merged subtrees: a shallow tree
     assert sum(s.info()["n_elems_local"] for s in shards) == ref.info()["n_elems_total"]
     b = np.random.default_rng(5).normal(size=3 * ref.n_nodes)
@@ -361,7 +363,8 @@ def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
     shards = [pkg.make_bar_system(*dims, rank=r, world=world, shard_mode=mode) for r in range(world)]
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
-        s.set_allreduce(hooks[r]); s.keep_z(False); s.initialize()
+        s.set_allreduce(hooks[r]); s.keep_z(False)
+    pkg.initialize_together(shards)
     infos = [s.info() for s in shards]
     assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"] and infos[0]["n_nodes"] == int(g["n_nodes"])
     if mode == "subtree":
@@ -402,7 +405,8 @@ def test_full_size_mixed_scene_in_8_shards_vs_compiled_reference(pkg):
     shards = [pkg.make_mixed_system(*[int(v) for v in g["bar_dims"]], *[int(v) for v in g["cloth"]], rank=r, world=world, shard_mode="subtree")[0] for r in range(world)]
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
-        s.set_allreduce(hooks[r]); s.keep_z(False); s.initialize()
+        s.set_allreduce(hooks[r]); s.keep_z(False)
+    pkg.initialize_together(shards)
     infos = [s.info() for s in shards]
     assert infos[0]["n_nodes"] == int(g["n_nodes"]) and sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"]
     out = [None] * world
@@ -454,7 +458,7 @@ def test_two_shards_on_one_gpu(pkg):
         return hook
     for r, s in enumerate(shards):
         s.set_allreduce(make_hook(r))
-        s.initialize()
+    pkg.initialize_together(shards)
     assert shards[0].info()["n_elems_local"] + shards[1].info()["n_elems_local"] == ref.info()["n_elems_total"]
     errs = []
 
@@ -674,7 +678,7 @@ def test_user_forces_sharded(pkg, monkeypatch, world, mode):
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
         s.set_allreduce(hooks[r])
-        s.initialize()
+    pkg.initialize_together(shards)
     assert sorted(np.concatenate([s.local_elements(0) for s in shards]).tolist()) == list(range(pairs.shape[0]))     # every user force on exactly one rank
     out = _run_sharded(shards, 3, 10, np.zeros(3 * ref.n_nodes))
     for r in range(world):

@@ -18,6 +18,7 @@ import json
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 
@@ -102,9 +103,10 @@ def main():
     bat = Baton(W, torch)
     for r, s in enumerate(shards):
         s.set_allreduce(bat.hook(r)); s.keep_z(False)
-    # initialize() does no collective: one after the other
-    for s in shards:
-        s.initialize()
+    # initialize() is a collective call under rank-local factorization (the default for subtree shards): one thread per rank
+    t_init0 = time.time()
+    pkg.initialize_together(shards)
+    t_init = time.time() - t_init0
     keys = ("local_ms", "rhs_ms", "solve_fwd_ms", "solve_bwd_ms", "allreduce_ms", "total_ms")
     acc = [[dict.fromkeys(keys, 0.0) for _ in range(a.frames)] for _ in range(W)]
     errs = []
@@ -137,7 +139,12 @@ def main():
     out = {"world": W, "mode": a.mode, "dims": a.dims, "frames": a.frames, "warm": a.warm, "iters": a.iters, 
            "all_ranks_bitwise_equal": bool(same), "finite": bool(np.isfinite(xs[0]).all()), "x_checksum": float(np.abs(xs[0]).sum()),
            "per_frame": [], "elements": [int(i["n_elems_local"]) for i in infos], "nodes_own": [int(i["nodes_own"]) for i in infos], "nodes_top": int(infos[0]["nodes_top"]),
-           "comm_bytes_per_iter": 8 * int(infos[0]["comm_doubles_iter"])}
+           "comm_bytes_per_iter": 8 * int(infos[0]["comm_doubles_iter"]),
+           # rank-local factorization: what every rank factors and keeps (one GPU hosts all ranks here, so the wall time is the SUM of the ranks' work)
+           "factor_local": [int(i["factor_local"]) for i in infos], "factor_gb_resident": [round(8e-9 * i["factor_doubles_resident"], 4) for i in infos],
+           "factor_gb_whole": round(1e-9 * infos[0]["panel_bytes"], 4), "front_gb": [round(8e-9 * i["front_doubles"], 4) for i in infos],
+           "factor_exchange_mb": round(8e-6 * infos[0]["factor_exchange_doubles"], 3), "t_numeric_s": [round(i["t_numeric_s"], 4) for i in infos],
+           "initialize_all_ranks_on_one_gpu_s": round(t_init, 3)}
     for f in range(a.frames):
         row = {k: [round(acc[r][f][k], 4) for r in range(W)] for k in keys if k not in ("allreduce_ms", "total_ms")}
         busy = [acc[r][f]["local_ms"] + acc[r][f]["rhs_ms"] + acc[r][f]["solve_fwd_ms"] + acc[r][f]["solve_bwd_ms"] for r in range(W)]
@@ -151,6 +158,9 @@ def main():
         W, a.mode, "x".join(map(str, a.dims)) if a.config == "bar" else "(mixed scene of configs[4])", a.warm, a.frames, a.iters, ""))
     print("elements per rank %s; nodes own %s + top %d; exchange %d bytes per iteration; all ranks bitwise equal: %s" % (
         out["elements"], out["nodes_own"], out["nodes_top"], out["comm_bytes_per_iter"], same))
+    print("factor: %s; resident per rank %s GB of %.3f GB (sum %.3f GB); fronts per rank %s GB; exchanged once per factorization %.1f MB; numeric phase per rank %s s" % (
+        "rank-local" if all(out["factor_local"]) else "whole on every rank", out["factor_gb_resident"], out["factor_gb_whole"], sum(out["factor_gb_resident"]), out["front_gb"],
+        out["factor_exchange_mb"], out["t_numeric_s"]))
     for f, row in enumerate(out["per_frame"]):
         print("frame %d  ms per ADMM iteration and rank (communication excluded)" % f)
         for k in ("local_ms", "rhs_ms", "solve_fwd_ms", "solve_bwd_ms", "busy_ms"):
