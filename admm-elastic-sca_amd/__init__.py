@@ -45,7 +45,7 @@ class Info(C.Structure):
                [(n, C.c_int64) for n in ("rhs_slots", "sweep_entries_own", "sweep_entries_top", "sweep_entries_top_bwd", "nodes_own", "nodes_top",
                                          "comm_doubles_iter", "comm_doubles_frame", "factor_doubles_resident", "front_doubles",
                                          "factor_exchange_doubles")] + \
-               [(n, C.c_int32) for n in ("factor_local", "reserved_")]
+               [(n, C.c_int32) for n in ("factor_local", "dist_top")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

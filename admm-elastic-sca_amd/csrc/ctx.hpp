@@ -142,6 +142,9 @@ struct admm_hip_ctx {
     // layout is then a compact one over those supernodes (dev_panel_off; -1 = not resident) -- Factor::panel_off stays the host layout.
     bool factor_local = true, factor_local_on = false;      // wanted / in effect (set by plan_device_panels at finalize)
     std::vector<int64_t> dev_panel_off, dev_root_inv_off; int64_t dev_panels_size = 0;
+    // distributed top (host_setup.cpp host_factor): the top of the tree is ONE root supernode, its product with the explicit inverse split by rows across the ranks
+    bool dist_top_wanted = true, dist_top = false;      // ADMM_HIP_DIST_TOP=0: the replicated top of rounds 2-5
+    int root_sn = -1, root_k = 0, root_first = 0, root_r0 = 0, root_r1 = 0; int64_t root_foff = 0;      // the root, this rank's rows [r0, r1) of its inverse (at dev_root_inv_off[root_sn])
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;
     int merge_small = 0;                          // dissection regions of at most that many nodes become four-way tree nodes (ADMM_HIP_MERGE_SMALL)

@@ -121,6 +121,7 @@ struct ND {
     bool merge_root = false;
     int merge_small = 0;      // regions of at most that many nodes (and more than a leaf) become four-way nodes as well: one level less near the leaves
     int root_depth = 0;       // > 1: bisection levels the ROOT node spans (whatever the other nodes do)
+    bool root_exact = false;  // root_depth >= 1 is binding: the root has exactly 2^root_depth children (subtree sharding's distributed top: one subtree per rank)
     int merge_depth = 2;      // bisection levels a merged node spans: 2 = four-way (three separators in one supernode), 3 = eight-way (seven)
     // the part `H` of a merged node: its separators down to `d` more bisections join `cols`, what is left below becomes children
     void gather(std::vector<int> &H, int d, int depth, std::vector<int> &kids, std::vector<int> &cols) {
@@ -136,6 +137,7 @@ struct ND {
         const int m = (int)nodes.size();
         if (m <= leaf) return emit(nodes);
         bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small) || (root_depth > 1 && depth == 0);
+        if (root_exact && depth == 0) four = root_depth > 1;      // the root spans EXACTLY root_depth bisection levels (1: a plain binary root), whatever the merge rules say
         std::vector<int> L, R, sep;
         bisect(nodes, L, R, sep);
         // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
@@ -160,7 +162,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth, bool root_exact) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -174,7 +176,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth;
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth; nd.root_exact = root_exact && root_depth >= 1;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
@@ -379,7 +381,7 @@ void plan_panels(Factor &F) {
     for (Supernode &S : F.sn) size += (int64_t)(S.ncols + S.nrows) * S.ncols;
     for (Supernode &S : F.sn) {
         S.root_inv_off = -1;
-        if (S.parent >= 0 || S.nrows != 0 || S.ncols <= ROOT_INV_MIN_COLS) continue;
+        if (S.parent >= 0 || S.nrows != 0 || S.ncols <= F.root_inv_min_cols) continue;
         const int64_t off = (size + 15) & ~(int64_t)15;
         S.root_inv_off = off;
         size = off + (int64_t)root_inv_ld(S.ncols) * S.ncols;
@@ -446,7 +448,7 @@ int factorize(const SymCSC &A, Factor &F, int threads) {
         for (int s = 0; s < ns; ++s) {
             Supernode &S = F.sn[s];
             S.root_inv_off = -1;
-            if (S.parent >= 0 || S.nrows != 0 || S.ncols <= ROOT_INV_MIN_COLS) continue;
+            if (S.parent >= 0 || S.nrows != 0 || S.ncols <= F.root_inv_min_cols) continue;
             const int k = S.ncols, ld = root_inv_ld(k);
             const size_t off = (F.panels.size() + 15) & ~(size_t)15;
             F.panels.resize(off + (size_t)ld * k, 0.0);

@@ -54,6 +54,7 @@ struct Factor {
     int64_t panels_size = 0;               // doubles in `panels` (plan_panels: the P_s, then the roots' inverses), also when the numeric phase runs on the GPU and `panels` stays empty
     int64_t nnz_tri = 0;                   // sum k(k+1)/2 + r k  (entries read per sweep)
     int max_cols = 0, max_rows = 0;
+    int root_inv_min_cols = ROOT_INV_MIN_COLS;   // roots with MORE columns than this get an explicit inverse (-1: every root -- the distributed top of subtree sharding needs it whatever the size)
     double t_order = 0, t_symbolic = 0, t_numeric = 0;
 };
 
@@ -67,8 +68,8 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 // merge_root: the top region alone does (one root supernode = top separator + the two half-separators)
 // merge_small > 0: regions of at most that many nodes (above the leaf size) become four-way nodes too (fewer, fatter levels near the leaves)
 // merge_depth: bisection levels a merged node spans (2: four-way nodes, 3: eight-way nodes with seven separators in one supernode);
-// root_depth > 1: the same for the root node alone
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0);
+// root_depth > 1: the same for the root node alone; root_exact: the root spans exactly root_depth >= 1 bisection levels (2^root_depth children)
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0, bool root_exact = false);
 
 // Layout of Factor::panels from the symbolic structure alone: Supernode::root_inv_off and Factor::panels_size.
 void plan_panels(Factor &F);

@@ -34,7 +34,7 @@ enum { GEMM_TRANS_A = 1, GEMM_TRANS_B = 2, GEMM_LOWER_TILES = 4, GEMM_K_FROM_COL
 struct GemmTask {
     const double *A, *B;
     double *C;
-    int m, n, k, lda, ldb, ldc, flags, pad;
+    int m, n, k, lda, ldb, ldc, flags, koff;      // koff: K_FROM_MAX counts the tile's column from here (C is a column slice [koff, koff + n) of the full product)
     double alpha, beta;
 };
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmTask *__restric
     const int i0 = ti << 6, j0 = tj << 6;
     int k0 = 0;
     if (T.flags & GEMM_K_FROM_COL) k0 = j0;
-    if (T.flags & GEMM_K_FROM_MAX) k0 = max(i0, j0);
+    if (T.flags & GEMM_K_FROM_MAX) k0 = max(i0, j0 + T.koff);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const bool ta = T.flags & GEMM_TRANS_A, tb = T.flags & GEMM_TRANS_B;

@@ -778,12 +778,14 @@ constexpr int ROOT_ROWS = ADMM_ROOT_ROWS;
 // GATHER (roots of at most ROOT_KCHUNK columns): every block forms t = y - (children's contributions) itself instead of reading the T a
 // root_gather_kernel launch wrote -- one launch less where a launch is 4-5 us of pure latency (mid-size systems); T then carries y.
 template <bool GATHER, bool CG2>
-__global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X,
+// nrows: rows of the product this launch computes -- Sinv points at the first of them, X at its x (the whole root: nrows = k; subtree sharding's
+// distributed top: this rank's slice of the rows, every row the same arithmetic whichever rank computes it).
+__global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int nrows, int ld, const double *__restrict__ Sinv, const double *__restrict__ T, double *__restrict__ X,
                                                                       int first, int64_t foff, FactorDev F, const double *__restrict__ C) {
     __shared__ double ts[ROOT_KCHUNK * 3 + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROOT_ROWS + wave;
-    const double *rp = Sinv + (size_t)min(row, k - 1) * ld;      // ld is a multiple of 16 doubles: every row starts on a 128-byte line
+    const double *rp = Sinv + (size_t)min(row, nrows - 1) * ld;      // ld is a multiple of 16 doubles: every row starts on a 128-byte line
     double v[3] = {0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < k; c0 += ROOT_KCHUNK) {
         const int kc = min(ROOT_KCHUNK, k - c0);
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(64 * ROOT_ROWS) void root_product_kernel(int k, int
     }
     int base = 0, cnt = 3;
     wave_sum_transpose<3, 32>(v, lane, base, cnt);
-    if (cnt >= 1 && row < k) X[3 * (size_t)row + base] = v[0];
+    if (cnt >= 1 && row < nrows) X[3 * (size_t)row + base] = v[0];
 }
 
 } // namespace admm_dev

@@ -69,6 +69,23 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     ctx->sn_owner.assign(ns, 0); ctx->node_owner.assign(F.n, 0);
     if (ctx->shard_mode != 1 || world <= 1) return;
     std::vector<double> load; int nt = 0; size_t nsub = 0;
+    if (ctx->dist_top) {      // distributed top: the root is the top, its children (one per rank, host_factor checked) are the ranks' subtrees in tree order
+        ctx->sn_owner.assign(ns, -2); load.assign(world, 0.0);
+        int next = 0;
+        for (int s = ns - 1; s >= 0; --s) {      // parents before children
+            if (F.sn[s].parent < 0) ctx->sn_owner[s] = -1;
+            else if (F.sn[s].parent == ns - 1) ctx->sn_owner[s] = -3;      // (numbered below, in ascending supernode order)
+            else ctx->sn_owner[s] = ctx->sn_owner[F.sn[s].parent];
+        }
+        std::vector<int> rank_of(ns, -1);
+        for (int s = 0; s < ns; ++s) if (ctx->sn_owner[s] == -3) rank_of[s] = next++;
+        for (int s = ns - 1; s >= 0; --s) {
+            if (F.sn[s].parent < 0) continue;
+            ctx->sn_owner[s] = F.sn[s].parent == ns - 1 ? rank_of[s] : ctx->sn_owner[F.sn[s].parent];
+            load[ctx->sn_owner[s]] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
+        }
+        nt = 1; nsub = (size_t)world;
+    } else
     subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
     for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];
     if (getenv("ADMM_HIP_VERBOSE")) {
@@ -137,11 +154,13 @@ void shard_accounting(admm_hip_ctx *ctx) {
     for (int s = 0; s < ns; ++s) {
         const int o = ctx->sn_owner[s];
         if (o == ctx->rank) { I.sweep_entries_own += entries(s); I.nodes_own += F.sn[s].ncols; }
+        else if (o < 0 && ctx->dist_top) { I.sweep_entries_top += (int64_t)(ctx->root_r1 - ctx->root_r0) * F.sn[s].ncols; I.nodes_top += F.sn[s].ncols; }      // this rank's rows of the root's inverse, once per iteration
         else if (o < 0) { I.sweep_entries_top += entries(s); I.nodes_top += F.sn[s].ncols; if (need[ctx->rank][s]) I.sweep_entries_top_bwd += entries(s); }
         const int par = F.sn[s].parent;
         if (o >= 0 && par >= 0 && ctx->sn_owner[par] < 0) slots += F.sn[s].nrows;      // roots of the owned subtrees: their contribution rows feed the top
     }
     I.comm_doubles_iter = 3 * (I.nodes_top + slots);      // [partial RHS on the top nodes | subtree roots' contribution rows]
+    if (ctx->dist_top) I.comm_doubles_iter += 3 * I.nodes_top;      // + the second collective: every rank's rows of the top's x
     I.comm_doubles_frame = 3 * (int64_t)F.n;               // the full x, once per frame (shard_sync_x)
 }
 
@@ -153,22 +172,34 @@ void plan_device_panels(admm_hip_ctx *ctx) {
     const int ns = (int)F.sn.size();
     ctx->factor_local_on = ctx->factor_local && ctx->shard_mode == 1 && ctx->world > 1 && ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce);
     ctx->dev_panel_off.assign(ns, -1); ctx->dev_root_inv_off.assign(ns, -1);
+    ctx->root_sn = -1;
+    if (!ctx->factor_local_on) ctx->dist_top = false;      // (host_factor asked the same questions; a small system solved densely switched the sharding off since)
     if (!ctx->factor_local_on) {
         for (int s = 0; s < ns; ++s) { ctx->dev_panel_off[s] = F.sn[s].panel_off; ctx->dev_root_inv_off[s] = F.sn[s].root_inv_off; }
         ctx->dev_panels_size = F.panels_size;
     } else {
         int64_t size = 0;
+        ctx->root_sn = -1;
         auto resident = [&](int s) { return ctx->sn_owner[s] == ctx->rank || ctx->sn_owner[s] < 0; };
-        for (int s = 0; s < ns; ++s) if (resident(s)) { ctx->dev_panel_off[s] = size; size += (int64_t)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols; }
+        // distributed top: of the root this rank keeps rows [r0, r1) of the explicit inverse and nothing else (its L^-1 and the whole inverse are
+        // temporaries of the factorization); slices start on multiples of 16 rows
+        if (ctx->dist_top) {
+            const int r = ns - 1, k = F.sn[r].ncols;
+            auto cut = [&](int q) { return q >= ctx->world ? k : (int)(((int64_t)k * q / ctx->world) & ~(int64_t)15); };
+            ctx->root_sn = r; ctx->root_k = k; ctx->root_first = F.sn[r].first; ctx->root_foff = F.sn[r].front_off;
+            ctx->root_r0 = cut(ctx->rank); ctx->root_r1 = cut(ctx->rank + 1);
+        }
+        for (int s = 0; s < ns; ++s) if (resident(s) && s != ctx->root_sn) { ctx->dev_panel_off[s] = size; size += (int64_t)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols; }
         for (int s = 0; s < ns; ++s) {
             if (!resident(s) || F.sn[s].root_inv_off < 0) continue;
             const int64_t off = (size + 15) & ~(int64_t)15;
             ctx->dev_root_inv_off[s] = off;
-            size = off + (int64_t)root_inv_ld(F.sn[s].ncols) * F.sn[s].ncols;
+            size = off + (int64_t)root_inv_ld(F.sn[s].ncols) * (s == ctx->root_sn ? ctx->root_r1 - ctx->root_r0 : F.sn[s].ncols);
         }
         ctx->dev_panels_size = size;
     }
     ctx->info.factor_local = ctx->factor_local_on ? 1 : 0;
+    ctx->info.dist_top = ctx->dist_top ? 1 : 0;
     ctx->info.factor_doubles_resident = ctx->dev_panels_size;
     ctx->info.front_doubles = 0; ctx->info.factor_exchange_doubles = 0;
     if (getenv("ADMM_HIP_VERBOSE") && ctx->world > 1)

@@ -135,6 +135,27 @@ def cpu_baseline(dims):
     return out
 
 
+def gpu_same_sample(pkg, dims, n_frames):
+    """The GPU on the SAME bounded sample the CPU leg times (same bar, same frames of the same simulation: frame 1 = warm-up, then n_frames
+    single frames of 20 ADMM iterations each, every one timed on its own like the CPU leg does) -- the only like-for-like pair of figures in
+    this line.  State resident, graph replay (this size is below 100k nodes), initialize excluded."""
+    nx, ny, nz = dims
+    s = pkg.make_bar_system(nx, ny, nz)
+    s.keep_z(False)
+    s.initialize()
+    s.step(ADMM_ITERS); s.sync()
+    per = []
+    for _ in range(n_frames):
+        t = time.perf_counter()
+        s.step(ADMM_ITERS); s.sync()
+        per.append((time.perf_counter() - t) / ADMM_ITERS)
+    assert np.isfinite(s.m_x).all()
+    best = min(per)
+    return {"ms_per_iter": 1e3 * best, "ms_per_iter_mean": 1e3 * float(np.mean(per)), "value": s.n_tets / best, "unit": "ADMM iters/s x elements",
+            "frames": "2..%d of the simulation, each timed on its own; the fastest one reported (what the CPU leg reports), the mean beside it" % (n_frames + 1),
+            "sample": "NH bar %dx%dx%d cubes = %d tets -- the cpu_baseline sample" % (nx, ny, nz, s.n_tets), "x_checksum": float(np.abs(s.m_x).sum())}
+
+
 def other_configs(pkg, torch, steps):
     """The throughput variants of the other BASELINE.json configs on this GPU, in this run:
     configs[1] 5,400-tet NH bar, configs[2] 50,700-tet StVK bar, configs[4] mixed scene (1 GPU).  Same protocol as the
@@ -664,6 +685,12 @@ def main():
                         "sweep_entries_own": int(info["sweep_entries_own"]), "sweep_entries_top": int(info["sweep_entries_top"]), "sweep_entries_top_bwd": int(info["sweep_entries_top_bwd"]),
                         "replicated_top_share_of_fwd_bytes": 8.0 * info["sweep_entries_top"] / fwd_bytes if fwd_bytes > 0 else 0.0,
                         "replicated_top_share_of_all_entries": info["sweep_entries_top"] / float(max(info["nnz_L"], 1))}
+        # System::initialize's ONE solver.compute(A) (System.cpp:138-140) across the ranks: rank-local = every rank assembles, factors and keeps its own
+        # subtrees + the replicated top (one all-reduce of the subtree roots' update matrices per factorization); otherwise the whole matrix on every rank
+        out["factor"] = {"rank_local": bool(info["factor_local"]), "whole_mb": 1e-6 * info["panel_bytes"], "resident_mb": 8e-6 * info["factor_doubles_resident"],
+                         "fronts_mb": 8e-6 * info["front_doubles"], "exchange_bytes_once": 8 * int(info["factor_exchange_doubles"]),
+                         "numeric_s": info["t_numeric_s"], "on": "gpu" if info.get("device_factor") else "host",
+                         "what": "rank 0's figures (per_rank.factor_mb_resident / front_mb / factor_numeric_s / initialize_s: every rank's)"}
         out["rccl_async_error"] = rccl_async
         out["graph_state"] = s.graph_state()
     if fake_world > 1:
@@ -672,13 +699,17 @@ def main():
     if world > 1:      # per-rank phase times (ms per ADMM iteration), element counts and bytes: where the scaling goes
         keys = ["local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms", "total_ms"]
         extra = ["elements", "tets", "fwd_bytes", "bwd_bytes", "nodes_own"]
-        vals = [phase[k] / iters_total for k in keys] + [float(info["n_elems_local"]), float(n_tets_local), fwd_bytes, bwd_bytes, float(info["nodes_own"])]
+        extra_f = ["factor_mb_resident", "front_mb", "factor_numeric_s", "initialize_s"]      # rank-local factorization: what every rank factored, kept, and how long its initialize took
+        vals = [phase[k] / iters_total for k in keys] + [float(info["n_elems_local"]), float(n_tets_local), fwd_bytes, bwd_bytes, float(info["nodes_own"])] + \
+               [8e-6 * info["factor_doubles_resident"], 8e-6 * info["front_doubles"], float(info["t_numeric_s"]), float(t_init)]
         mine = torch.tensor(vals, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         out["per_rank"] = {k: [round(float(t[i]), 4) for t in allr] for i, k in enumerate(keys)}
         for j, k in enumerate(extra):
             out["per_rank"][k] = [int(t[len(keys) + j]) for t in allr]
+        for j, k in enumerate(extra_f):
+            out["per_rank"][k] = [round(float(t[len(keys) + len(extra) + j]), 4) for t in allr]
         out["per_rank_summary"] = {k: {"slowest": max(out["per_rank"][k]), "fastest": min(out["per_rank"][k])} for k in keys}
         out["rccl_ranks_seen"] = ranks_seen              # head count from a checked all-reduce through the path config.allreduce names
         out["ranks_ok"] = bool(ranks_seen == a.gpus == world)
@@ -736,6 +767,12 @@ def main():
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 side figure
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_dims)
+                try:      # the like-for-like pair: the GPU on the CPU leg's own sample and frames (ms per ADMM iteration side by side; no ratio to the headline size)
+                    cb = out["cpu_baseline"]
+                    cb["gpu_same_sample"] = gpu_same_sample(pkg, a.cpu_dims, 2 * max(1, len(cb.get("ms_per_iter_by_team", {}))))
+                    cb["same_sample_ms_per_iter"] = {"cpu_%s_%d_threads" % (cb["kind"], cb["cores"]): cb["ms_per_iter"], "gpu": cb["gpu_same_sample"]["ms_per_iter"]}
+                except Exception as e:  # noqa: BLE001
+                    out["cpu_baseline"]["gpu_same_sample"] = {"error": repr(e)}
             except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "ADMM iters/s x elements", "cores": 0, "kind": "unavailable", "sample": repr(e)}
         print(json.dumps(out))

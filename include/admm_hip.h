@@ -301,7 +301,9 @@ typedef struct admm_hip_info {
     int64_t front_doubles;           /* doubles of frontal matrices this rank's numeric factorization held at once (0: factored on the host) */
     int64_t factor_exchange_doubles; /* doubles summed across the ranks ONCE per factorization (the subtree roots' update matrices) */
     int32_t factor_local;            /* 1: this rank factored only its own subtrees + the replicated top                          */
-    int32_t reserved_;
+    int32_t dist_top;                /* 1: distributed top -- the top of the tree is ONE root supernode whose product with its explicit inverse is split
+                                        by rows across the ranks (subtree shards of 2 / 4 / 8 / 16 ranks; ADMM_HIP_DIST_TOP=0: replicated top): two small
+                                        collectives per ADMM iteration instead of one, no replicated sweep                                         */
 } admm_hip_info;
 int admm_hip_get_info(admm_hip_ctx *ctx, admm_hip_info *info);
 /* Rank-local factorization (default on; ADMM_HIP_FACTOR_LOCAL=0 / 1 overrides).  Under subtree sharding with world > 1 a rank sweeps

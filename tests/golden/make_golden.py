@@ -19,6 +19,7 @@ Fixtures
   traj_dillo_nh.npz    poordillo mesh (2761 NH tets), gravity + anchored hand/foot, 3 frames (the reference bifurcates at frame 4 under 1-ulp perturbations)
   traj_bunny_stvk.npz  bunnyexpand mesh (2510 StVK tets), x scaled x1.3 after initialize, 2 frames (chaotic afterwards: 1-ulp sensitivity > 1e-3)
   traj_cloth.npz       30x20 sym-plane cloth, TriangleStrain + Bend + 2 anchors, 3 frames x 30 iters
+  traj_bar_nh_5400.npz, traj_bar_stvk_50700.npz   the throughput sizes of BASELINE.json configs[1] / [2] (make_baseline_bars)
   assembly_bar.npz     global_idx, W diagonal and D triplets in the reference's own row layout
   traj_collision.npz   plinkopony-like: corotational tets falling on cylinders / sphere / floor (CollisionForce)
 """
@@ -180,6 +181,41 @@ def make_bars():
                         D_rows=rr[k], D_cols=rc[k], D_vals=rv[k], rows=r.rows)
 
 
+def make_baseline_bars():
+    """The two THROUGHPUT sizes of BASELINE.json configs[1] / configs[2] as SURVEY 8(d) fixes them (bench.py other_configs times them):
+    Neo-Hookean bar 10x10x9 cubes = 5 400 tets, StVK bar 13x13x50 = 50 700 tets, mu = lambda = 1e5, 20 iterations per frame.
+      x_frames / ulp_sensitivity   3 frames from rest + the reference's own 1-ulp sensitivity per frame (5 seeds)
+      *_one_iter                   ONE ADMM iteration from checkers.deformed_start (+ and * only: the same bits everywhere), scaled so that the
+                                   deformation gradients of these short bars sit 5-20 % off the identity: x, v after the frame; u, z (the 9 real
+                                   rows of the reference's 36 per tet), warm-start state and L-BFGS iteration count of every `tet_stride`-th tet,
+                                   u / z of every anchor -- the local step sees bit-identical input on every implementation."""
+    from checkers import deformed_start
+    for name, kind, dims, tstride, scale in (("nh_5400", KIND["TET_NH"], (10, 10, 9), 1, 10.0), ("stvk_50700", KIND["TET_STVK"], (13, 13, 50), 8, 3.0)):
+        r = bar_system(Ref, kind, dims, 1e5, 1e5, 20)
+        X = []
+        for _ in range(3):
+            r.step(); X.append(r.x.copy())
+        ENV = envelope(lambda: bar_system(Ref, kind, dims, 1e5, 1e5, 20), 3)
+        r1 = bar_system(Ref, kind, dims, 1e5, 1e5, 1)
+        x0 = r1.x.copy()
+        r1.x = deformed_start(x0 * scale) / scale      # (the polynomial terms act on the scaled coordinates: short bars deform like the 8 m one)
+        r1.step()
+        nt = 6 * dims[0] * dims[1] * dims[2]; na = (dims[0] + 1) * (dims[1] + 1)
+        u = r1.u; z = r1.z
+        assert u.size == 36 * nt + 3 * na
+        ut = u[:36 * nt].reshape(nt, 36); zt = z[:36 * nt].reshape(nt, 36)
+        assert not ut[:, 9:].any() and not zt[:, 9:].any()
+        tets = np.arange(0, nt, tstride)
+        st = np.zeros((tets.size, 4)); it = np.zeros(tets.size, np.int32)
+        for k, e in enumerate(tets):
+            st[k], it[k] = r1.hyper_state(int(e))
+        np.savez_compressed(os.path.join(HERE, "traj_bar_%s.npz" % name), dims=np.array(dims), kind=kind, mu=1e5, lam=1e5, max_iter=5, dt=0.04, iters=20,
+                            x_frames=np.array(X), ulp_sensitivity=np.array(ENV), start_scale=scale, tet_stride=tstride,
+                            x_one_iter=r1.x, v_one_iter=r1.v, u_tets=ut[tets, :9], z_tets=zt[tets, :9], state_tets=st, n_iters_tets=it,
+                            u_anchors=u[36 * nt:].reshape(na, 3), z_anchors=z[36 * nt:].reshape(na, 3))
+        print("baseline bar", name, "1-ulp sensitivity per frame", ENV, "max |u| after the deformed iteration %.3e" % np.abs(ut).max(), "L-BFGS iterations", np.bincount(it))
+
+
 def load_tetmesh(path_base, scale):
     """TetGen .node/.ele (first column = index).  Vertices pass through float32
     like trimesh2's Vec<3,float> (reference src/ForceBuilder.hpp:132-135)."""
@@ -327,6 +363,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "skin":
         make_skin()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "baseline_bars":
+        make_baseline_bars()
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "projects":      # e.g.  make_golden.py projects TRI_AREA TRI_FUNG
         make_projects(sys.argv[2:])
         sys.exit(0)
@@ -334,6 +373,7 @@ if __name__ == "__main__":
     make_projects()
     make_known_answers()
     make_bars()
+    make_baseline_bars()
     make_meshes()
     make_cloth()
     make_skin()

@@ -522,6 +522,40 @@ def test_bar_one_iteration_and_trajectory(pkg, name, kind):
         assert np.abs(s.m_x - o.x).max() < tol(g, f)
 
 
+@pytest.mark.parametrize("name", ["nh_5400", "stvk_50700"])
+def test_baseline_throughput_sizes(pkg, name):
+    """BASELINE.json configs[1] / configs[2] at the sizes bench.py times them (Neo-Hookean bar 10x10x9 = 5 400 tets --
+    the explicit-inverse solve --, StVK bar 13x13x50 = 50 700 tets -- panel sweeps; 20 iterations per frame) against the oracle and the
+    compiled reference's fixtures (tests/golden/make_golden.py baseline_bars):
+      * ONE ADMM iteration from a strongly deformed start (checkers.deformed_start: + and * only): the local step sees bit-identical input,
+        so u, z, the warm start and the L-BFGS iteration counts are BIT-EXACT for every tet and anchor (oracle: all of them; reference: the
+        recorded ones); x after the solve <= 1e-11, v <= 1e-9;
+      * three frames from rest inside 20 x the reference's own 1-ulp sensitivity (the envelope every trajectory fixture uses)."""
+    from checkers import deformed_start
+    g = golden("traj_bar_%s.npz" % name)
+    dims = tuple(int(v) for v in g["dims"]); kind = int(g["kind"]); sc = float(g["start_scale"])
+    s, o = _bar_pair(pkg, kind, dims, 1)
+    x0 = deformed_start(s.m_x * sc) / sc
+    s.m_x = x0; o.x = x0
+    s.step(1); o.step()
+    nt = 6 * dims[0] * dims[1] * dims[2]
+    tets = np.arange(0, nt, int(g["tet_stride"]))
+    lt, la = s.read_local(0), s.read_local(1)
+    ou = o.u; oz = o.z
+    assert np.array_equal(lt["u"], ou[:9 * nt].reshape(nt, 9)) and np.array_equal(lt["z"], oz[:9 * nt].reshape(nt, 9))          # every tet, vs the oracle
+    assert np.array_equal(la["u"], ou[9 * nt:].reshape(-1, 3)) and np.array_equal(la["z"], oz[9 * nt:].reshape(-1, 3))
+    assert np.array_equal(lt["u"][tets], g["u_tets"]) and np.array_equal(lt["z"][tets], g["z_tets"])                              # the recorded ones, vs the compiled reference
+    assert np.array_equal(lt["state"][tets], g["state_tets"]) and np.array_equal(lt["n_iters"][tets], g["n_iters_tets"])
+    assert np.array_equal(la["u"], g["u_anchors"]) and np.array_equal(la["z"], g["z_anchors"])
+    assert np.abs(s.m_x - g["x_one_iter"]).max() < 1e-11 and np.abs(s.m_x - o.x).max() < 1e-11
+    assert np.abs(s.m_v - g["v_one_iter"]).max() < 1e-9
+    s, o = _bar_pair(pkg, kind, dims, int(g["iters"]))
+    for f in range(3):
+        s.step(int(g["iters"])); o.step()
+        assert np.abs(s.m_x - g["x_frames"][f]).max() < tol(g, f), (f, np.abs(s.m_x - g["x_frames"][f]).max())
+        assert np.abs(s.m_x - o.x).max() < tol(g, f), f
+
+
 def test_known_answers(pkg):
     g = golden("known_answers.npz")
     s = pkg.System(device_id=0); s.set_timestep(1.0)
@@ -844,6 +878,47 @@ def test_full_size_bar_vs_compiled_reference(pkg):
     assert err < bound, (err, bound)
     assert abs(np.abs(x).sum() - float(g["sum_abs"])) < bound * x.size
     assert abs((x * x).sum() - float(g["sum_sq"])) < bound * x.size
+
+
+def test_full_size_bar_one_iteration_vs_compiled_reference(pkg):
+    """The TIGHT check at the headline size (tests/golden/traj_bar_1M_one_iter.npz, make_golden_fullsize.py one_iter: the compiled reference
+    on the 1,001,472-tet Neo-Hookean bar, 1 064 s of initialize).  (1) Its solver.solve(b) for three right-hand sides, at every 8th node:
+    <= 1e-10 x max|x| -- the bound of the small solve fixtures, here on the benchmark's own factor.  (2) ONE ADMM iteration from a strongly
+    deformed start built from + and * only (checkers.deformed_start: the same bits on every host): the local step of all 1 001 472 tets
+    sees bit-identical input, so u, z, the warm start and the L-BFGS iteration counts of the recorded tets (every 64th) and of all 1 089
+    anchors are BIT-EXACT; the sums of |u|, u^2, |z|, z^2 over ALL tets agree to summation-order rounding; x after the one solve <= 1e-10,
+    v = (x - x_old) / dt <= 1e-8 -- no 20-iteration chaos in between (the 20-iteration frame: test_full_size_bar_vs_compiled_reference)."""
+    import os
+    from checkers import deformed_start, solve_rhs
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_bar_1M_one_iter.npz")):
+        pytest.skip("full-size fixture not generated")
+    g = golden("traj_bar_1M_one_iter.npz")
+    dims = [int(v) for v in g["dims"]]
+    s = pkg.make_bar_system(*dims)
+    s.initialize()
+    assert s.n_nodes == int(g["n_nodes"])
+    st = int(g["stride"])
+    x0 = s.m_x.copy()
+    mx, mt = pkg.meshgen.bar(*dims)
+    B = solve_rhs(int(g["solve_seed"]), x0, np.repeat(pkg.meshgen.lumped_tet_mass(mx, mt, 1000.0), 3))      # (m_masses as make_golden.bar_system set them)
+    for k in range(3):
+        xs = s.solve_only(B[k]).reshape(-1, 3)[::st]
+        assert np.abs(xs - g["solve_x_sample"][k]).max() < 1e-10 * float(g["solve_x_max"][k]), (k, np.abs(xs - g["solve_x_sample"][k]).max())
+    s.m_x = deformed_start(x0)
+    s.step(1)
+    nt = 6 * dims[0] * dims[1] * dims[2]
+    tets = np.arange(0, nt, int(g["tet_stride"]))
+    lt, la = s.read_local(0), s.read_local(1)
+    assert np.array_equal(lt["u"][tets], g["u_tets"]) and np.array_equal(lt["z"][tets], g["z_tets"])
+    assert np.array_equal(lt["state"][tets], g["state_tets"]) and np.array_equal(lt["n_iters"][tets], g["n_iters_tets"])
+    assert np.array_equal(la["u"], g["u_anchors"]) and np.array_equal(la["z"], g["z_anchors"])
+    for arr, key in ((np.abs(lt["u"]).sum(), "u_sum_abs"), ((lt["u"] ** 2).sum(), "u_sum_sq"), (np.abs(lt["z"]).sum(), "z_sum_abs"), ((lt["z"] ** 2).sum(), "z_sum_sq")):
+        assert abs(arr - float(g[key])) <= 1e-11 * abs(float(g[key])), key
+    x = s.m_x.reshape(-1, 3)
+    err = np.abs(x[::st] - g["x_sample"]).max()
+    assert err < 1e-10, err
+    assert np.abs(s.m_v.reshape(-1, 3)[::st] - g["v_sample"]).max() < 1e-8
+    assert abs(np.abs(x).sum() - float(g["sum_abs"])) < 1e-10 * x.size
 
 
 def test_full_size_mixed_vs_compiled_reference(pkg):

@@ -175,6 +175,8 @@ def test_sharding_knobs(pkg, monkeypatch, knob, value):
         ref.step(8); refx.append(ref.m_x.copy())
     world = 2
     monkeypatch.setenv(knob, value)
+    if knob == "ADMM_HIP_SUBTREES_PER_RANK":
+        monkeypatch.setenv("ADMM_HIP_DIST_TOP", "0")      # (a knob of the replicated top's partition; the distributed top deals exactly one subtree per rank)
     caller_mode = "subtree" if value == "contiguous" else ("contiguous" if knob == "ADMM_HIP_SHARD" else "subtree")      # the environment must win over the caller
     shards = [_bar(pkg, "TET_LINEAR", [4000.0], dims=dims, rank=r, world=world, mode=caller_mode) for r in range(world)]
     hooks = _hooks(world)

@@ -85,6 +85,32 @@ def _bar(kind, dims, iters, ref_layout=False):
     return o
 
 
+@pytest.mark.parametrize("name", ["nh_5400", "stvk_50700"])
+def test_baseline_throughput_sizes(name):
+    """The two throughput sizes of BASELINE.json configs[1] / configs[2] (NH bar 10x10x9 = 5 400 tets, StVK bar 13x13x50 = 50 700 tets,
+    20 iterations per frame) -- the oracle against the compiled reference's fixtures (make_golden.py baseline_bars): ONE ADMM iteration from a
+    strongly deformed start -- u, z, warm start and L-BFGS iteration counts of the recorded tets and of every anchor BIT-EXACT, x to 1e-11 --
+    and three frames from rest inside 20 x the reference's own 1-ulp sensitivity."""
+    from checkers import deformed_start
+    g = golden("traj_bar_%s.npz" % name)
+    dims = tuple(int(v) for v in g["dims"]); kind = int(g["kind"]); sc = float(g["start_scale"])
+    o = _bar(kind, dims, 1)
+    o.x = deformed_start(o.x * sc) / sc
+    o.step()
+    nt = 6 * dims[0] * dims[1] * dims[2]
+    tets = np.arange(0, nt, int(g["tet_stride"]))
+    u = o.u; z = o.z
+    assert np.array_equal(u[:9 * nt].reshape(nt, 9)[tets], g["u_tets"]) and np.array_equal(z[:9 * nt].reshape(nt, 9)[tets], g["z_tets"])
+    assert np.array_equal(u[9 * nt:].reshape(-1, 3), g["u_anchors"]) and np.array_equal(z[9 * nt:].reshape(-1, 3), g["z_anchors"])
+    st = np.array([o.hyper_state(int(e))[0] for e in tets]); it = np.array([o.hyper_state(int(e))[1] for e in tets])
+    assert np.array_equal(st, g["state_tets"]) and np.array_equal(it, g["n_iters_tets"])
+    assert np.abs(o.x - g["x_one_iter"]).max() < 1e-11 and np.abs(o.v - g["v_one_iter"]).max() < 1e-9
+    o = _bar(kind, dims, int(g["iters"]))
+    for f in range(3):
+        o.step()
+        assert np.abs(o.x - g["x_frames"][f]).max() < tol(g, f), f
+
+
 def test_assembly_indexing_bit_exact():
     """global_idx, W and D in the reference's own row layout (36 rows per tet)."""
     g = golden("assembly_bar.npz")

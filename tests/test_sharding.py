@@ -297,6 +297,7 @@ def test_backward_over_the_top_only_where_a_rank_reads_it(pkg, monkeypatch):
     (ADMM_HIP_TOP_BWD_ALL=1), and so is the solve-only entry point."""
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
     monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    monkeypatch.setenv("ADMM_HIP_DIST_TOP", "0")           # the REPLICATED top (what 3 / 5 / 6 ... ranks always run; 8 ranks by default split ONE root's product by rows instead)
     # long thin bars: the ranks' subtrees are slabs, a rank reads 2 of the 5 (world 8) resp. 2 - 5 of the 8 (world 6) top separators
     # (tools/probe/top_needed_verbose.py prints the counts)
     for world, dims in ((8, (4, 4, 120)), (6, (5, 5, 90))):
@@ -319,6 +320,43 @@ def test_backward_over_the_top_only_where_a_rank_reads_it(pkg, monkeypatch):
                 assert np.array_equal(res["0"][r][1][f], res["1"][r][1][f]), (world, r, f)
             assert np.array_equal(res["0"][r][2], res["1"][r][2])
             assert np.array_equal(res["0"][r][1][-1], res["0"][0][1][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
+    """Subtree shards of 2 / 4 / 8 ranks, the two designs of the top of the elimination tree side by side: DISTRIBUTED (round 6, the default: the
+    separators of the first log2(world) bisection levels are ONE root supernode; every rank keeps and streams only its rows of the root's explicit
+    inverse, the slices of x meet in a second small all-reduce) and REPLICATED (ADMM_HIP_DIST_TOP=0: every rank sweeps a multi-level top).  Both
+    solve the single-rank system to 1e-10, both end a frame bitwise equal on all ranks; the distributed top leaves a rank less factor than the
+    replicated one and nothing to sweep backward above its own subtrees."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    dims = (6, 6, 64)
+    ref = pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"]); ref.initialize()
+    b = np.random.default_rng(9).normal(size=3 * ref.n_nodes)
+    xref = ref.solve_only(b)
+    infos = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("ADMM_HIP_DIST_TOP", knob)
+        shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world, shard_mode="subtree") for r in range(world)]
+        hooks = _thread_allreduce_hooks(world)
+        for r, s in enumerate(shards):
+            s.set_allreduce(hooks[r])
+        pkg.initialize_together(shards)
+        out = _run_sharded(shards, 2, 10, b)
+        infos[knob] = [s.info() for s in shards]
+        for r in range(world):
+            assert np.abs(out[r][0] - xref).max() < 1e-10 * np.abs(xref).max(), (knob, r)
+            assert np.array_equal(out[r][1][-1], out[0][1][-1]) and np.array_equal(out[r][2], out[0][2]), (knob, r)
+        assert sum(i["n_elems_local"] for i in infos[knob]) == ref.info()["n_elems_total"]
+    d, rp = infos["1"], infos["0"]
+    assert all(i["dist_top"] == 1 and i["factor_local"] == 1 for i in d) and all(i["dist_top"] == 0 for i in rp)
+    assert all(i["sweep_entries_top_bwd"] == 0 for i in d)
+    k = d[0]["nodes_top"]
+    assert sum(i["sweep_entries_top"] for i in d) == k * k                      # the ranks' row slices tile the root's inverse exactly
+    assert sum(i["nodes_own"] for i in d) + k == ref.n_nodes
+    assert d[0]["comm_doubles_iter"] > 3 * k                                     # two collectives: [top RHS | contribution rows] and the top's x
 
 
 @pytest.mark.gpu
@@ -535,6 +573,69 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert abs(one["value"] - 2 * 20 / (one["ms_per_step"] * 2e-3) * 8 * 8 * 40 * 6) < 1e-6 * one["value"]
     # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
+
+
+_BENCH_NRANK_ARGS = ["--steps", "2", "--warmup", "1", "--dims", "12", "12", "60", "--no-cpu-baseline", "--no-extras"]      # 10 309 nodes: panel sweeps, a top of several levels at 8 ranks
+_bench_one_rank_cache = {}
+
+
+def _bench_one_rank_line():
+    import json
+    if "line" not in _bench_one_rank_cache:
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + _BENCH_NRANK_ARGS, capture_output=True, text=True, timeout=900)
+        assert r1.returncode == 0, r1.stderr[-2000:]
+        _bench_one_rank_cache["line"] = json.loads(r1.stdout.strip().splitlines()[-1])
+    return _bench_one_rank_cache["line"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_n_ranks_end_to_end(n):
+    """`python bench.py --gpus 4` / `--gpus 8` exactly as typed -- what the driver's first multi-GPU commands are: bench.py starts its N ranks
+    itself (fresh torch.distributed.run child), every rank a REAL process with its own context; on this one-GPU box they share cuda:0 and gloo
+    stands in for RCCL (bench.py's test hooks).  N processes through the consensus bootstrap, the rank-local factorization (initialize is a
+    collective: the subtree roots' update matrices meet in one all-reduce), the subtree partition with a replicated top of several levels,
+    the N-way per_rank gather: rc 0, ONE JSON line, a head count of N through the very all-reduce path the iterations use, every per_rank
+    list N long, the ranks' elements a partition, every rank factored only its share, the final positions those of the one-rank run."""
+    import json
+    one = _bench_one_rank_line()
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + _BENCH_NRANK_ARGS, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    L = json.loads(lines[0])
+    assert L["n_gpus"] == n and L["steps"] == 2 and L["value"] > 0 and L["scaling"] == "strong"
+    assert L["rccl_ranks_seen"] == n and L["ranks_ok"] is True and "gloo" in L["config"]["allreduce"]
+    pr = L["per_rank"]
+    for k in ("local_ms", "rhs_ms", "allreduce_ms", "solve_fwd_ms", "solve_bwd_ms", "total_ms", "elements", "tets", "fwd_bytes", "bwd_bytes", "nodes_own",
+              "factor_mb_resident", "factor_numeric_s"):
+        assert len(pr[k]) == n, k
+    assert sum(pr["elements"]) == 12 * 12 * 60 * 6 + 13 * 13 and sum(pr["tets"]) == 12 * 12 * 60 * 6 and min(pr["elements"]) > 0
+    sh = L["shard"]
+    assert sh["mode"] == "subtree" and sum(pr["nodes_own"]) + sh["nodes_top"] == 13 * 13 * 61 and sh["nodes_top"] > 0
+    fl = L["factor"]
+    assert fl["rank_local"] is True and fl["exchange_bytes_once"] > 0
+    assert max(pr["factor_mb_resident"]) < fl["whole_mb"] and sum(pr["factor_mb_resident"]) < fl["whole_mb"] * (1.0 + n * sh["replicated_top_share_of_all_entries"] + 0.3)
+    assert L["rccl_async_error"] == 0
+    assert abs(L["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_a_hung_collective_exits_nonzero():
+    """Eight real processes, rank 5 stops reaching the collective in a timed frame: every watchdog ends its rank within the per-frame limit, the
+    launcher relays a non-zero code, no JSON line."""
+    import time
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5", ADMM_BENCH_FRAME_TIMEOUT_MAX="10",
+               ADMM_BENCH_TEST_HANG_RANK="5", ADMM_BENCH_TEST_HANG_AFTER="34")      # initialize: 2 calls; warm-up frame: 20 + the frame's x; then the 12th iteration of timed frame 0
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + _BENCH_NRANK_ARGS, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "no progress for" in r.stderr and "timed frame" in r.stderr and "exiting with code 3" in r.stderr
+    assert time.time() - t < 600
 
 
 def test_bench_refuses_a_rank_count_that_is_not_gpus():

@@ -28,8 +28,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 class Baton:
     """all-reduce between `world` contexts of one process + the serialising baton (see the module docstring)"""
 
-    def __init__(self, world, torch):
-        self.world, self.torch = world, torch
+    def __init__(self, world, torch, serialise=True):
+        self.world, self.torch, self.serialise = world, torch, serialise
         self.cv = threading.Condition()
         self.arrived = [0] * world          # exchanges rank r has entered
         self.summed = 0                     # exchanges whose sum is complete
@@ -67,7 +67,7 @@ class Baton:
                 else:
                     ok = self.cv.wait_for(lambda: self.failed or self.summed >= c + 1, timeout=600)
                     # the baton: the rank before me has done its post-exchange work and reached the NEXT exchange (or is through)
-                    ok = ok and self.cv.wait_for(lambda: self.failed or self.finished[r - 1] or self.arrived[r - 1] >= c + 2, timeout=600)
+                    ok = ok and (not self.serialise or self.cv.wait_for(lambda: self.failed or self.finished[r - 1] or self.arrived[r - 1] >= c + 2, timeout=600))
                     if not ok or self.failed:
                         self.failed = True; self.cv.notify_all(); return 1
             return 0
@@ -100,13 +100,15 @@ def main():
         shards = [pkg.make_mixed_system(26, 26, 123, 158, 158, rank=r, world=W, shard_mode=a.mode)[0] for r in range(W)]
     else:
         shards = [pkg.make_bar_system(*a.dims, rank=r, world=W, shard_mode=a.mode) for r in range(W)]
-    bat = Baton(W, torch)
+    bat0, bat = Baton(W, torch, serialise=False), Baton(W, torch)
     for r, s in enumerate(shards):
-        s.set_allreduce(bat.hook(r)); s.keep_z(False)
+        s.set_allreduce(bat0.hook(r)); s.keep_z(False)      # (initialize: plain sums -- a rank that is through must not wait for a next exchange)
     # initialize() is a collective call under rank-local factorization (the default for subtree shards): one thread per rank
     t_init0 = time.time()
     pkg.initialize_together(shards)
     t_init = time.time() - t_init0
+    for r, s in enumerate(shards):
+        s.set_allreduce(bat.hook(r))
     keys = ("local_ms", "rhs_ms", "solve_fwd_ms", "solve_bwd_ms", "allreduce_ms", "total_ms")
     acc = [[dict.fromkeys(keys, 0.0) for _ in range(a.frames)] for _ in range(W)]
     errs = []
