@@ -70,17 +70,11 @@ void partition_subtrees(admm_hip_ctx *ctx) {
     if (ctx->shard_mode != 1 || world <= 1) return;
     std::vector<double> load; int nt = 0; size_t nsub = 0;
     if (ctx->dist_top) {      // distributed top: the root is the top, its children (one per rank, host_factor checked) are the ranks' subtrees in tree order
-        ctx->sn_owner.assign(ns, -2); load.assign(world, 0.0);
+        ctx->sn_owner.assign(ns, -1); load.assign(world, 0.0);
         int next = 0;
-        for (int s = ns - 1; s >= 0; --s) {      // parents before children
-            if (F.sn[s].parent < 0) ctx->sn_owner[s] = -1;
-            else if (F.sn[s].parent == ns - 1) ctx->sn_owner[s] = -3;      // (numbered below, in ascending supernode order)
-            else ctx->sn_owner[s] = ctx->sn_owner[F.sn[s].parent];
-        }
         std::vector<int> rank_of(ns, -1);
-        for (int s = 0; s < ns; ++s) if (ctx->sn_owner[s] == -3) rank_of[s] = next++;
-        for (int s = ns - 1; s >= 0; --s) {
-            if (F.sn[s].parent < 0) continue;
+        for (int s = 0; s < ns; ++s) if (F.sn[s].parent == ns - 1) rank_of[s] = next++;      // the root's children, in ascending supernode order
+        for (int s = ns - 2; s >= 0; --s) {      // parents before children
             ctx->sn_owner[s] = F.sn[s].parent == ns - 1 ? rank_of[s] : ctx->sn_owner[F.sn[s].parent];
             load[ctx->sn_owner[s]] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
         }
@@ -170,7 +164,8 @@ void shard_accounting(admm_hip_ctx *ctx) {
 void plan_device_panels(admm_hip_ctx *ctx) {
     const Factor &F = ctx->F;
     const int ns = (int)F.sn.size();
-    ctx->factor_local_on = ctx->factor_local && ctx->shard_mode == 1 && ctx->world > 1 && ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce);
+    // (ADMM_HIP_PLAN_AS_IF_DEVICE: the CPU tests' host-only contexts plan the sharding as a context with a device and a transport would)
+    ctx->factor_local_on = ctx->factor_local && ctx->shard_mode == 1 && ctx->world > 1 && ((ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce)) || getenv("ADMM_HIP_PLAN_AS_IF_DEVICE"));
     ctx->dev_panel_off.assign(ns, -1); ctx->dev_root_inv_off.assign(ns, -1);
     ctx->root_sn = -1;
     if (!ctx->factor_local_on) ctx->dist_top = false;      // (host_factor asked the same questions; a small system solved densely switched the sharding off since)

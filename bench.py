@@ -421,6 +421,7 @@ def main():
         s.set_factor_local(False)      # ONE rank's share with identity "sums": the top of the tree can only be factored whole
     if fake_world > 1 and not fake_dist:
         s.set_allreduce(lambda ptr, count, strm: 0)
+    hang = None
     if world > 1 or fake_dist:
         n3 = None
         holder = {}
@@ -429,11 +430,11 @@ def main():
             def __init__(self, ptr, count):
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
-        hang = {"calls": 0, "rank": int(os.environ.get("ADMM_BENCH_TEST_HANG_RANK", "-1")), "after": int(os.environ.get("ADMM_BENCH_TEST_HANG_AFTER", "0"))}
+        hang = {"calls": 0, "rank": int(os.environ.get("ADMM_BENCH_TEST_HANG_RANK", "-1")), "after": int(os.environ.get("ADMM_BENCH_TEST_HANG_AFTER", "0")), "armed": False}
 
         def torch_hook(ptr, count, strm):
             hang["calls"] += 1
-            if hang["rank"] == rank and hang["calls"] > hang["after"]:      # test hook (tests/test_sharding.py): this rank never reaches the collective again
+            if hang["armed"] and hang["rank"] == rank and hang["calls"] > hang["after"]:      # test hook (tests/test_sharding.py): this rank never reaches the collective again
                 time.sleep(1e6)
             t = holder.get(ptr)
             if t is None:
@@ -491,6 +492,8 @@ def main():
     # lost launch overlap each): around every iteration they cost 3.7 % at one GPU, around every 10th 0.7 % (tools/probe/event_overhead.py).
     s.enable_timing(a.timing_stride)
     phase = dict(local_ms=0.0, rhs_ms=0.0, allreduce_ms=0.0, solve_fwd_ms=0.0, solve_bwd_ms=0.0, total_ms=0.0)
+    if hang is not None:
+        hang["calls"] = 0; hang["armed"] = True      # (test hook: ADMM_BENCH_TEST_HANG_AFTER counts the collectives of the TIMED region, however many initialize and the warm-up issued)
     t0 = time.perf_counter()
     for f in range(a.steps):
         wd.beat("timed frame %d: queueing" % f, frame_limit)
@@ -664,7 +667,8 @@ def main():
                                    "HIP events between the phases of every %d-th ADMM iteration (eager launches; %d samples per kernel feed roofline), "
                                    "event-free launches otherwise (eager at this size; one graph replay per iteration below 100k nodes)" % (a.timing_stride, a.steps * (ADMM_ITERS // a.timing_stride))),
                    "allreduce": (comm_path if (world > 1 or fake_dist) else None), "parallelism": ("1 GPU" if world == 1 else
-                                   ("x%d: elements and elimination subtrees per rank, one small all-reduce (top separators) per ADMM iteration, top of the solve replicated" % world
+                                   (("x%d: elements and elimination subtrees per rank, %s" % (world, "two small all-reduces per ADMM iteration (top rows in, the top's x out), the top's product split by rows across the ranks"
+                                                                                                 if info["dist_top"] else "one small all-reduce (top separators) per ADMM iteration, top of the solve replicated"))
                                     if a.shard == "subtree" else "x%d: contiguous element shards, RHS all-reduce per ADMM iteration, replicated solve" % world)),
                    "nnz_L": info["nnz_L"], "supernodes": info["n_supernodes"], "levels": info["n_levels"],
                    "initialize_s": t_init, "factor_numeric_s": info["t_numeric_s"],
@@ -675,8 +679,11 @@ def main():
     if world > 1 or fake_dist or fake_world > 1:
         # the exchange, as the library accounts for it (admm_hip_info.comm_doubles_*): ONE collective per ADMM iteration (subtree shards: the
         # packed top rows; contiguous: the whole right-hand side) + under subtree shards one more per frame (the full x before the velocity update)
-        out["comm"] = {"path": comm_path if (world > 1 or fake_dist) else "no-op hook (fake world)", "collectives_per_iter": 1 if info["comm_doubles_iter"] else 0,
-                       "bytes_per_collective": 8 * int(info["comm_doubles_iter"]),
+        out["comm"] = {"path": comm_path if (world > 1 or fake_dist) else "no-op hook (fake world)", "collectives_per_iter": (2 if info["dist_top"] else 1) if info["comm_doubles_iter"] else 0,
+                       "bytes_per_iter": 8 * int(info["comm_doubles_iter"]),
+                       "bytes_per_collective": ([8 * int(info["comm_doubles_iter"] - 3 * info["nodes_top"]), 8 * 3 * int(info["nodes_top"])] if info["dist_top"] else 8 * int(info["comm_doubles_iter"])),
+                       "top": ("distributed: ONE root supernode (%d nodes), every rank streams its rows of the explicit inverse, the slices of x meet in the second collective" % info["nodes_top"]) if info["dist_top"]
+                              else "replicated: every rank sweeps the top levels of the tree",
                        "collectives_per_frame_extra": 1 if info["comm_doubles_frame"] else 0, "bytes_per_frame_extra": 8 * int(info["comm_doubles_frame"]),
                        "allreduce_ms_per_iter": phase["allreduce_ms"] / iters_total,
                        "what": "allreduce_ms = pack + ncclAllReduce + unpack (subtree) resp. ncclAllReduce of the RHS (contiguous) between HIP events on the solver's "

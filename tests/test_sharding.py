@@ -136,6 +136,39 @@ def test_subtree_partition_properties(pkg, monkeypatch, world):
     assert loads.sum() == t.shape[0] + anchors.size and loads.max() < 1.6 * loads.mean()
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_distributed_top_partition(pkg, monkeypatch, world):
+    """The distributed top's plan, host side (a host-only context planning as a context with a device and a transport would:
+    ADMM_HIP_PLAN_AS_IF_DEVICE): ONE top supernode = the separators of the first log2(world) bisection levels, one subtree per rank; the ranks'
+    row slices of the root's explicit inverse tile it exactly; every rank keeps its own subtrees' panels + its slice, nobody the whole factor;
+    the elements partition; every rank computes the same plan."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    monkeypatch.setenv("ADMM_HIP_PLAN_AS_IF_DEVICE", "1")
+    dims = (6, 6, 48)
+    systems = []
+    for r in range(world):
+        s = pkg.make_bar_system(*dims, device_id=-1, rank=r, world=world, shard_mode="subtree")
+        s.initialize()
+        systems.append(s)
+    infos = [s.info() for s in systems]
+    owner = systems[0].node_owner()
+    assert all(np.array_equal(s.node_owner(), owner) for s in systems[1:])
+    assert all(i["dist_top"] == 1 and i["factor_local"] == 1 for i in infos)
+    k = infos[0]["nodes_top"]
+    assert k == int((owner == -1).sum()) and 0 < k < 0.4 * owner.size and sorted(set(owner.tolist())) == [-1] + list(range(world))
+    assert sum(i["sweep_entries_top"] for i in infos) == k * k and all(i["sweep_entries_top_bwd"] == 0 for i in infos)
+    assert sum(i["nodes_own"] for i in infos) + k == owner.size
+    whole = infos[0]["panel_bytes"] // 8
+    assert all(i["factor_doubles_resident"] < whole for i in infos)
+    assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"]
+    assert all(i["comm_doubles_iter"] == infos[0]["comm_doubles_iter"] for i in infos) and infos[0]["comm_doubles_iter"] >= 6 * k
+    # without the knob a host-only context (no device, no transport) plans the replicated top of rounds 2-5
+    monkeypatch.delenv("ADMM_HIP_PLAN_AS_IF_DEVICE")
+    s = pkg.make_bar_system(*dims, device_id=-1, rank=0, world=world, shard_mode="subtree"); s.initialize()
+    assert s.info()["dist_top"] == 0 and s.info()["factor_local"] == 0
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_subtree_partition_unstructured(pkg, monkeypatch, world):
     """The same properties on an unstructured mesh (Delaunay tets of random points: 5-60 tets per node)."""
@@ -557,8 +590,9 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     for k, v in two["per_rank_summary"].items():
         assert v["slowest"] >= v["fastest"] >= 0 and v["slowest"] == max(pr[k])
     cm, sh, inf1 = two["comm"], two["shard"], one["config"]
-    assert cm["collectives_per_iter"] == 1 and cm["collectives_per_frame_extra"] == 1 and cm["allreduce_ms_per_iter"] > 0
-    assert cm["bytes_per_frame_extra"] == 8 * 3 * 9 * 9 * 41 and 0 < cm["bytes_per_collective"] < cm["bytes_per_frame_extra"]      # the top rows only, not the whole RHS
+    assert cm["collectives_per_iter"] == 2 and cm["collectives_per_frame_extra"] == 1 and cm["allreduce_ms_per_iter"] > 0           # distributed top: [top rows in | the top's x out]
+    assert cm["bytes_per_frame_extra"] == 8 * 3 * 9 * 9 * 41 and 0 < cm["bytes_per_iter"] < cm["bytes_per_frame_extra"]      # the top rows only, not the whole RHS
+    assert len(cm["bytes_per_collective"]) == 2 and sum(cm["bytes_per_collective"]) == cm["bytes_per_iter"] and cm["bytes_per_collective"][1] == 8 * 3 * sh["nodes_top"] and cm["top"].startswith("distributed")
     assert sh["mode"] == "subtree" and sh["nodes_top"] > 0 and sh["nodes_own"] == pr["nodes_own"][0] and sum(pr["nodes_own"]) + sh["nodes_top"] == 9 * 9 * 41
     assert sh["sweep_entries_top_bwd"] <= sh["sweep_entries_top"] and 0 < sh["replicated_top_share_of_fwd_bytes"] < 1
     assert two["rccl_async_error"] == 0 and "graph_state" in two
@@ -628,7 +662,7 @@ def test_bench_eight_ranks_a_hung_collective_exits_nonzero():
     launcher relays a non-zero code, no JSON line."""
     import time
     env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5", ADMM_BENCH_FRAME_TIMEOUT_MAX="10",
-               ADMM_BENCH_TEST_HANG_RANK="5", ADMM_BENCH_TEST_HANG_AFTER="34")      # initialize: 2 calls; warm-up frame: 20 + the frame's x; then the 12th iteration of timed frame 0
+               ADMM_BENCH_TEST_HANG_RANK="5", ADMM_BENCH_TEST_HANG_AFTER="13")      # the 14th collective of the timed region: the 7th iteration of timed frame 0 (two per iteration under the distributed top)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     t = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + _BENCH_NRANK_ARGS, capture_output=True, text=True, timeout=900, env=env)
@@ -692,7 +726,7 @@ def test_bench_two_ranks_a_hung_collective_exits_nonzero():
     import time
     args = ["--steps", "2", "--warmup", "1", "--dims", "8", "8", "40", "--no-cpu-baseline"]
     env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_BENCH_FRAME_TIMEOUT_MIN="5", ADMM_BENCH_FRAME_TIMEOUT_MAX="10",
-               ADMM_BENCH_TEST_HANG_RANK="1", ADMM_BENCH_TEST_HANG_AFTER="30")      # warm-up frame: 20 calls + the frame's x; then the 10th iteration of timed frame 0
+               ADMM_BENCH_TEST_HANG_RANK="1", ADMM_BENCH_TEST_HANG_AFTER="13")      # the 14th collective of the timed region: the 7th iteration of timed frame 0 (two per iteration under the distributed top)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     t = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=600, env=env)

@@ -141,7 +141,9 @@ def main():
     out = {"world": W, "mode": a.mode, "dims": a.dims, "frames": a.frames, "warm": a.warm, "iters": a.iters, 
            "all_ranks_bitwise_equal": bool(same), "finite": bool(np.isfinite(xs[0]).all()), "x_checksum": float(np.abs(xs[0]).sum()),
            "per_frame": [], "elements": [int(i["n_elems_local"]) for i in infos], "nodes_own": [int(i["nodes_own"]) for i in infos], "nodes_top": int(infos[0]["nodes_top"]),
-           "comm_bytes_per_iter": 8 * int(infos[0]["comm_doubles_iter"]),
+           "comm_bytes_per_iter": 8 * int(infos[0]["comm_doubles_iter"]), "dist_top": int(infos[0]["dist_top"]),
+           "top_gb_streamed_per_iter": [round(8e-9 * (i["sweep_entries_top"] + i["sweep_entries_top_bwd"]), 4) for i in infos],
+           "own_gb_streamed_per_iter": [round(8e-9 * 2 * i["sweep_entries_own"], 4) for i in infos],
            # rank-local factorization: what every rank factors and keeps (one GPU hosts all ranks here, so the wall time is the SUM of the ranks' work)
            "factor_local": [int(i["factor_local"]) for i in infos], "factor_gb_resident": [round(8e-9 * i["factor_doubles_resident"], 4) for i in infos],
            "factor_gb_whole": round(1e-9 * infos[0]["panel_bytes"], 4), "front_gb": [round(8e-9 * i["front_doubles"], 4) for i in infos],
@@ -160,6 +162,9 @@ def main():
         W, a.mode, "x".join(map(str, a.dims)) if a.config == "bar" else "(mixed scene of configs[4])", a.warm, a.frames, a.iters, ""))
     print("elements per rank %s; nodes own %s + top %d; exchange %d bytes per iteration; all ranks bitwise equal: %s" % (
         out["elements"], out["nodes_own"], out["nodes_top"], out["comm_bytes_per_iter"], same))
+    print("top of the tree: %s; a rank streams per iteration: own subtrees (both sweeps) %s GB, top %s GB" % (
+        "DISTRIBUTED (one root supernode, its product split by rows; two collectives per iteration)" if out["dist_top"] else "replicated (every rank sweeps it; one collective per iteration)",
+        out["own_gb_streamed_per_iter"], out["top_gb_streamed_per_iter"]))
     print("factor: %s; resident per rank %s GB of %.3f GB (sum %.3f GB); fronts per rank %s GB; exchanged once per factorization %.1f MB; numeric phase per rank %s s" % (
         "rank-local" if all(out["factor_local"]) else "whole on every rank", out["factor_gb_resident"], out["factor_gb_whole"], sum(out["factor_gb_resident"]), out["front_gb"],
         out["factor_exchange_mb"], out["t_numeric_s"]))
