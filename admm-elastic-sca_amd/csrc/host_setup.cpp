@@ -170,7 +170,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         int root_depth = 0;
         if (const char *e = getenv("ADMM_HIP_ROOT_DEPTH")) root_depth = atoi(e);
         // Distributed top (round 6; subtree shards of 2 / 4 / 8 / 16 ranks with rank-local factorization): the separators of the first log2(world)
-        // bisection levels form ONE root supernode whose children are the ranks' subtrees, one each.  The root is solved as a single product with its
+        // bisection levels (at least two) form ONE root supernode whose children are the ranks' subtrees, one each (2 ranks: two each).  The root is solved as a single product with its
         // explicit inverse (what merge_root does on one GPU), and that product is split by rows across the ranks -- every rank streams 1 / world of
         // the inverse and the slices meet in a second small collective -- instead of every rank sweeping a replicated top of several levels: the
         // replicated top's bytes grow with the rank count (4M-tet bar: 0.85 GB at 4 ranks, 1.66 GB of a rank's 2.4 GB at 8), the split root's shrink.
@@ -178,15 +178,16 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         if (own_subtrees && ctx->dist_top_wanted && ctx->factor_local && ctx->root_inverse && ((ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce)) || getenv("ADMM_HIP_PLAN_AS_IF_DEVICE")) &&
             (ctx->world & (ctx->world - 1)) == 0 && ctx->world <= 16 && ctx->n_nodes > ctx->dense_max && !getenv("ADMM_HIP_ROOT_DEPTH") && !getenv("ADMM_HIP_MERGE_ROOT")) {
             int d = 0; while ((1 << d) < ctx->world) ++d;
+            d = std::max(d, 2);      // (2 ranks: four subtrees, two per rank -- the merged-root tree of rounds 2-5; one level less inside a rank's subtrees than a two-way root)
             Factor T;
             analyze(ctx->A, xyz.data(), leaf, T, merge_above, false, merge_small, merge_depth, d, true);
             const int ns = (int)T.sn.size();
             int roots = 0, kids = 0; bool ok = ns > 0;
             for (int sn = 0; sn < ns; ++sn) { if (T.sn[sn].parent < 0) ++roots; else if (T.sn[sn].parent == ns - 1) ++kids; }
-            ok = ok && roots == 1 && kids == ctx->world && T.sn[ns - 1].ncols > 0;
+            ok = ok && roots == 1 && kids == (1 << d) && T.sn[ns - 1].ncols > 0;
             // (the split product pays its second collective only where a rank's slice is real work; the explicit inverse must fit beside the fronts)
             if (ok) { ctx->F = std::move(T); ctx->F.root_inv_min_cols = -1; ctx->dist_top = true; }
-            else if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: distributed top: the dissection gives %d roots / %d subtrees for %d ranks -- replicated top instead\n", roots, kids, ctx->world);
+            else if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: distributed top: the dissection gives %d roots / %d subtrees (wanted %d for %d ranks) -- replicated top instead\n", roots, kids, 1 << d, ctx->world);
         }
         if (!ctx->dist_top)
         analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth);

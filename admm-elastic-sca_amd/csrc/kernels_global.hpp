@@ -720,9 +720,10 @@ __global__ __launch_bounds__(64 * NWB) void solve_bwd_kernel(const SweepItem *__
 // independent of the others -- streams the inverse: 1089 columns in ~6 us where the tile kernel's 16 waves x 68 dependent
 // columns needed 20 us, and a merged 3335-column root (ND::merge_root) at HBM rate.
 template <bool CG2>
-__global__ __launch_bounds__(256) void root_gather_kernel(int k, int first, int64_t foff, FactorDev F, const double *__restrict__ y, const double *__restrict__ C, double *__restrict__ T) {
+__global__ __launch_bounds__(256) void root_gather_kernel(int k, int first, int64_t foff, FactorDev F, const double *__restrict__ y, const double *__restrict__ C, double *__restrict__ T, double *__restrict__ Xzero = nullptr) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= k) return;
+    if (Xzero) { Xzero[3 * (size_t)j] = 0.0; Xzero[3 * (size_t)j + 1] = 0.0; Xzero[3 * (size_t)j + 2] = 0.0; }      // (distributed top: x of the root's rows other ranks compute -- zeros go into the exchange)
     double s0, s1, s2;
     child_sum<CG2>(F, foff + j, C, s0, s1, s2);
     const double *src = y + 3 * (size_t)(first + j);

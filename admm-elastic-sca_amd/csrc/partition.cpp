@@ -73,12 +73,15 @@ void partition_subtrees(admm_hip_ctx *ctx) {
         ctx->sn_owner.assign(ns, -1); load.assign(world, 0.0);
         int next = 0;
         std::vector<int> rank_of(ns, -1);
-        for (int s = 0; s < ns; ++s) if (F.sn[s].parent == ns - 1) rank_of[s] = next++;      // the root's children, in ascending supernode order
+        int n_kids = 0;
+        for (int s = 0; s < ns; ++s) if (F.sn[s].parent == ns - 1) ++n_kids;
+        const int per_rank = std::max(1, n_kids / world);      // (a power of two of subtrees, host_factor checked: 2 ranks hold two each, neighbours in the dissection)
+        for (int s = 0; s < ns; ++s) if (F.sn[s].parent == ns - 1) rank_of[s] = std::min(world - 1, next++ / per_rank);      // the root's children, in ascending supernode order
         for (int s = ns - 2; s >= 0; --s) {      // parents before children
             ctx->sn_owner[s] = F.sn[s].parent == ns - 1 ? rank_of[s] : ctx->sn_owner[F.sn[s].parent];
             load[ctx->sn_owner[s]] += (double)(F.sn[s].ncols + F.sn[s].nrows) * F.sn[s].ncols;
         }
-        nt = 1; nsub = (size_t)world;
+        nt = 1; nsub = (size_t)n_kids;
     } else
     subtree_owners(F, world, ctx->sn_owner, load, nt, nsub);
     for (int s = 0; s < ns; ++s) for (int j = 0; j < F.sn[s].ncols; ++j) ctx->node_owner[F.sn[s].first + j] = ctx->sn_owner[s];

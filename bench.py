@@ -560,7 +560,9 @@ def main():
     valu = None
     sweeps = None
     bound = "hbm"
-    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r05/pmc_1M.json"))
+    pmc_file = os.path.join("profiles", os.environ.get("ADMM_BENCH_PMC", "r06/pmc_1M.json"))
+    if not os.path.exists(os.path.join(ROOT, pmc_file)):
+        pmc_file = os.path.join("profiles", "r05/pmc_1M.json")
     if not os.path.exists(os.path.join(ROOT, pmc_file)):
         pmc_file = os.path.join("profiles", "r04/pmc_1M.json")
     pmc_stamp_ok = None      # True / False: the counter file carries the hash of the sources it was collected on (None: an unstamped, older file)
@@ -601,7 +603,9 @@ def main():
                 valu.update(measured_roof(pm, sec))
                 bound = "valu"
         if a.config == "mixed" and world == 1 and dom.startswith("project_multi_kernel"):      # the scene's one-launch local step: counters of tools/pmc_collect.sh with PMC_MIXED=1
-            pmc_file = os.path.join("profiles", "r05", "pmc_mixed.json")
+            pmc_file = os.path.join("profiles", "r06", "pmc_mixed.json")
+            if not os.path.exists(os.path.join(ROOT, pmc_file)):
+                pmc_file = os.path.join("profiles", "r05", "pmc_mixed.json")
             if not os.path.exists(os.path.join(ROOT, pmc_file)):
                 pmc_file = os.path.join("profiles", "r04", "pmc_mixed.json")
             kern = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]

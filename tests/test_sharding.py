@@ -388,6 +388,32 @@ def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
     assert all(i["sweep_entries_top_bwd"] == 0 for i in d)
     k = d[0]["nodes_top"]
     assert sum(i["sweep_entries_top"] for i in d) == k * k                      # the ranks' row slices tile the root's inverse exactly
+    # recompute_weights is collective too (every rank re-factors its share, the subtree roots' update matrices meet again): the anchors' weights
+    # down to 0.5, every third tet's doubled -- the sharded solve of the NEW system equals the single-rank solve of the new system
+    shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world, shard_mode="subtree") for r in range(world)]
+    hooks = _thread_allreduce_hooks(world)
+    for r, s in enumerate(shards):
+        s.set_allreduce(hooks[r])
+    pkg.initialize_together(shards)
+    wt = ref.read_rest(0)["weight"].copy(); wt[::3] *= 2.0
+    wa = np.full(ref.read_rest(1)["weight"].size, 0.5)
+    sol = [None] * world; errs = []
+
+    def rew(r, s):
+        try:
+            s.set_weights(0, wt); s.set_weights(1, wa); s.recompute_weights()
+            sol[r] = s.solve_only(b)
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+    ref.set_weights(0, wt); ref.set_weights(1, wa); ref.recompute_weights()
+    xnew = ref.solve_only(b)
+    th = [threading.Thread(target=rew, args=(r, s)) for r, s in enumerate(shards)]
+    [t.start() for t in th]; [t.join(timeout=300) for t in th]
+    assert not errs and all(x is not None for x in sol), errs
+    assert np.abs(xnew - xref).max() > 1e-6 * np.abs(xref).max()                 # (the weights did change the system)
+    for r in range(world):
+        assert np.abs(sol[r] - xnew).max() < 1e-10 * np.abs(xnew).max(), r
+        assert np.array_equal(sol[r], sol[0])
     assert sum(i["nodes_own"] for i in d) + k == ref.n_nodes
     assert d[0]["comm_doubles_iter"] > 3 * k                                     # two collectives: [top RHS | contribution rows] and the top's x
 

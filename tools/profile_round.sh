@@ -3,7 +3,7 @@
 # bench_1M_kernel_stats.csv, level_trace_1M.txt, ranks_one_gpu.txt, ranks_one_gpu_contiguous.txt, bench_mixed.json};
 # copy them into profiles/rNN/ afterwards.   usage: tools/profile_round.sh [rNN]
 cd $GRAFT_REPO_ROOT
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/prof
 mkdir -p $O
 export TMPDIR=/tmp
