@@ -169,7 +169,7 @@ def other_configs(pkg, torch, steps):
         for _ in range(warm):       # warm-up frames (graph capture, cost-ordered launch, clocks) up to the STATED state ...
             s.step(ADMM_ITERS)
         s.sync()
-        # ... which is kept (x, v, every force's u and warm start: the checkpoint of DESIGN 6d) and restored before each of the three timed
+        # ... which is kept (x, v, every force's u and warm start: the checkpoint of DESIGN section 7) and restored before each of the three timed
         # runs: all three time the SAME frames warm+1 .. warm+steps of the simulation (the local step's cost moves with the deformation:
         # consecutive windows of one simulation are not repeat measurements)
         ck = dict(x=s.m_x.copy(), v=s.m_v.copy(), loc=[s.read_local(b) for b in range(len(s.batches))])

@@ -105,7 +105,7 @@ def test_scene_through_class_api(pkg, tmp_path, typ):
         else:
             o.set_control_point(h, np.array(list(o.force(h).pos)), False)
         o.step(); elapsed += 0.04
-        assert np.abs(X[fr] - o.x).max() < 2e-4, fr       # within the truncated-prox sensitivity (DESIGN.md 4.6)
+        assert np.abs(X[fr] - o.x).max() < 2e-4, fr       # within the truncated-prox sensitivity (DESIGN.md section 4)
     assert np.abs(cp_final - np.array(list(o.force(h).pos))).max() < 2e-4
 
 
@@ -217,7 +217,7 @@ def test_scene_through_class_api_multi_rank(pkg, tmp_path, world, mode):
     (X1, _), (Xw, _) = run(2, 1, "a")
     assert np.abs(Xw[0] - X1[0]).max() < 1e-11
     # ten iterations per frame, five frames: the truncated StVK prox amplifies last-bit differences of its input (the reference
-    # against itself from a 1-ulp perturbed start: 2e-6 after one frame, DESIGN.md 4.6); the released control point (frames 3, 4)
+    # against itself from a 1-ulp perturbed start: 2e-6 after one frame, DESIGN.md section 4); the released control point (frames 3, 4)
     # is the reference's value on every rank -- Dx of the last project() (AnchorForce.cpp:80-83), i.e. the node BEFORE the last
     # global solve: the owner rank's state travels through admm_hip_allreduce_host
     (X1, cp1), (Xw, cpw) = run(5, 10, "b")
@@ -317,7 +317,7 @@ def _check_dillo(out, g, release):
     else:
         ref, env, frames = g["x_release"], g["ulp_sensitivity_release"], [int(f) for f in g["release_keep"]]
     # The reference's own resolution: its trajectory moves by `env` when its start moves by 1-3 ulps (truncated L-BFGS +
-    # Armadillo contacts, DESIGN.md 4.6).  Two separate claims:
+    # Armadillo contacts, DESIGN.md section 4).  Two separate claims:
     #  (1) PRE-CHAOS frames (the reference still agrees with itself to < 1e-4; frames 0-2 here): a tight bound, 3 x the reference's
     #      own sensitivity (measured: 0.5-1.2 x) -- a regression of the solver shows up HERE and cannot hide behind (2);
     #  (2) frames after the reference's own bifurcation (its 1-ulp twin is 5e-3 .. 3e-2 away): these assert the same macroscopic

@@ -678,7 +678,7 @@ def test_residuals_and_early_exit(pkg):
     sb.enable_residuals(True); ob.track_residuals(True)
     sb.step(12); ob.step()
     r, sd, it = sb.residuals(); ro, so, _ = ob.residuals()
-    # the truncated L-BFGS amplifies the rounding differences of the two solvers within the frame (DESIGN.md 4.6)
+    # the truncated L-BFGS amplifies the rounding differences of the two solvers within the frame (DESIGN.md section 4)
     assert it == 12 and np.abs(r - ro).max() < 1e-4 * ro.max() and np.abs(sd - so).max() < 1e-4 * so.max()
 
 

@@ -261,7 +261,7 @@ def test_sharded_step_matches_single_rank(pkg, monkeypatch, world, mode):
     """`world` shards of one scene on ONE GPU (one context and one host thread per rank, meeting in the all-reduce hook)
     against the unsharded step, plus the solve-only entry point.  Subtree sharding exchanges only the top separators' rows
     per iteration and rebuilds x once per frame.  Cloth (triangle strain + bend + anchors: no truncated minimiser): tight.
-    StVK bar: the sums meet in another order and the truncated L-BFGS amplifies that (DESIGN.md 4.6): 1e-5 over 3 frames."""
+    StVK bar: the sums meet in another order and the truncated L-BFGS amplifies that (DESIGN.md section 4): 1e-5 over 3 frames."""
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")          # the panel sweeps, not the small-system inverse
     monkeypatch.setenv("ADMM_HIP_LEAF", "16")              # a deep elimination tree on a small mesh
     from conftest import golden
@@ -440,7 +440,7 @@ def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
     for r in range(world):
         sol, xs, vs = out[r]
         assert np.abs(sol - xref).max() < 1e-10 * np.abs(xref).max(), (r, "solve")
-        assert np.abs(xs[0] - ref.m_x).max() < 2e-5, (r, np.abs(xs[0] - ref.m_x).max())      # (the sums meet in another order; the truncated L-BFGS amplifies that: DESIGN 4.6)
+        assert np.abs(xs[0] - ref.m_x).max() < 2e-5, (r, np.abs(xs[0] - ref.m_x).max())      # (the sums meet in another order; the truncated L-BFGS amplifies that: DESIGN section 4)
         assert np.array_equal(xs[0], out[0][1][0]) and np.array_equal(vs, out[0][2])
 
 
@@ -572,7 +572,7 @@ def test_two_shards_on_one_gpu(pkg):
         x0, x1, xr = shards[0].m_x, shards[1].m_x, ref.m_x
         assert np.array_equal(x0, x1)                      # replicated solve: identical on every rank
         # = unsharded, up to the order of the fp64 partial sums (first frame: rounding only;
-        # later frames: amplified by the truncated prox, DESIGN.md 4.6)
+        # later frames: amplified by the truncated prox, DESIGN.md section 4)
         assert np.abs(x0 - xr).max() < (1e-11 if frame == 0 else 1e-6)
 
 
@@ -631,7 +631,7 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     # the N = 1 line from the same code: same schema minus the rank objects, value = frames * iters / wall * tets
     assert "per_rank" not in one and "comm" not in one and one["n_gpus"] == 1
     assert abs(one["value"] - 2 * 20 / (one["ms_per_step"] * 2e-3) * 8 * 8 * 40 * 6) < 1e-6 * one["value"]
-    # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames (DESIGN.md 4.6)
+    # the partial sums meet in a different order; the NH bar amplifies that to ~1e-7 over three frames (DESIGN.md section 4)
     assert abs(two["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
 
 
