@@ -143,7 +143,10 @@ struct admm_hip_ctx {
     bool factor_local = true, factor_local_on = false;      // wanted / in effect (set by plan_device_panels at finalize)
     std::vector<int64_t> dev_panel_off, dev_root_inv_off; int64_t dev_panels_size = 0;
     // distributed top (host_setup.cpp host_factor): the top of the tree is ONE root supernode, its product with the explicit inverse split by rows across the ranks
-    bool dist_top_wanted = true, dist_top = false;      // ADMM_HIP_DIST_TOP=0: the replicated top of rounds 2-5
+    // ADMM_HIP_DIST_TOP = 0: the replicated top of rounds 2-5, 1: distributed whatever the size; default (-1): distributed from dist_top_min_nodes nodes on -- its
+    // second collective per iteration costs more than it saves on small systems (1M-tet bar, 178.6k nodes, 8 ranks: the slowest rank's kernels 0.264 -> 0.253 ms for one
+    // more all-reduce; 4M tets, 693k nodes: 1.113 -> 0.689 ms)
+    int dist_top_wanted = -1, dist_top_min_nodes = 300000; bool dist_top = false;
     int root_sn = -1, root_k = 0, root_first = 0, root_r0 = 0, root_r1 = 0; int64_t root_foff = 0;      // the root, this rank's rows [r0, r1) of its inverse (at dev_root_inv_off[root_sn])
     bool tet_order = true; int tet_order_min_blocks = 3072;      // NH / StVK batches of more blocks than that start their costliest blocks first (ADMM_HIP_TET_ORDER=0: mesh order)
     int64_t frames = 0;

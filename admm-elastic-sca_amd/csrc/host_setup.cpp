@@ -175,7 +175,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // the inverse and the slices meet in a second small collective -- instead of every rank sweeping a replicated top of several levels: the
         // replicated top's bytes grow with the rank count (4M-tet bar: 0.85 GB at 4 ranks, 1.66 GB of a rank's 2.4 GB at 8), the split root's shrink.
         ctx->dist_top = false;
-        if (own_subtrees && ctx->dist_top_wanted && ctx->factor_local && ctx->root_inverse && ((ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce)) || getenv("ADMM_HIP_PLAN_AS_IF_DEVICE")) &&
+        if (own_subtrees && (ctx->dist_top_wanted == 1 || (ctx->dist_top_wanted < 0 && ctx->n_nodes >= ctx->dist_top_min_nodes)) && ctx->factor_local && ctx->root_inverse && ((ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce)) || getenv("ADMM_HIP_PLAN_AS_IF_DEVICE")) &&
             (ctx->world & (ctx->world - 1)) == 0 && ctx->world <= 16 && ctx->n_nodes > ctx->dense_max && !getenv("ADMM_HIP_ROOT_DEPTH") && !getenv("ADMM_HIP_MERGE_ROOT")) {
             int d = 0; while ((1 << d) < ctx->world) ++d;
             d = std::max(d, 2);      // (2 ranks: four subtrees, two per rank -- the merged-root tree of rounds 2-5; one level less inside a rank's subtrees than a two-way root)

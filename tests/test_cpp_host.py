@@ -175,13 +175,15 @@ def test_comm_helpers_on_the_cpu(pkg, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,mode", [(2, 1), (3, 1), (2, 0), (4, 1), (8, 1)])
-def test_scene_through_class_api_multi_rank(pkg, tmp_path, world, mode):
+def test_scene_through_class_api_multi_rank(pkg, tmp_path, monkeypatch, world, mode):
     """Multi-GPU from the C++ class API (System::shard; System.hpp:29-76 has no counterpart -- the reference's element loop is
     one OpenMP team, System.cpp:57-58): `world` PROCESSES each build the whole scene of scene_bar.cpp and own a shard of its
     elements (mode 1: elimination subtrees, 0: contiguous ranges); on this one-GPU box they share the GPU and meet in
     comm::ShmAllReduce instead of RCCL.  Every rank ends every frame with the complete, identical m_x, equal to the
     single-process run up to the order of the partial sums."""
     mg = pkg.meshgen
+    if world >= 4:
+        monkeypatch.setenv("ADMM_HIP_DIST_TOP", "1")      # the distributed top (two collectives per iteration) through the class API; by default only from 300k nodes on
     dims = (8, 8, 40) if world < 4 else (12, 12, 60)      # 3321 nodes: beyond the explicit-inverse solve, so the subtree split is real; 4 / 8 ranks (round 6: what the first
     x, t = mg.bar(*dims)                                   # multi-GPU run starts -- 8 real processes, rank-local factorization, a top of several levels): 10 309 nodes
     m = mg.lumped_tet_mass(x, t, 1000.0)

@@ -145,6 +145,7 @@ def test_distributed_top_partition(pkg, monkeypatch, world):
     monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
     monkeypatch.setenv("ADMM_HIP_LEAF", "16")
     monkeypatch.setenv("ADMM_HIP_PLAN_AS_IF_DEVICE", "1")
+    monkeypatch.setenv("ADMM_HIP_DIST_TOP", "1")           # (by default only from 300k nodes on)
     dims = (6, 6, 48)
     systems = []
     for r in range(world):
@@ -163,6 +164,14 @@ def test_distributed_top_partition(pkg, monkeypatch, world):
     assert all(i["factor_doubles_resident"] < whole for i in infos)
     assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"]
     assert all(i["comm_doubles_iter"] == infos[0]["comm_doubles_iter"] for i in infos) and infos[0]["comm_doubles_iter"] >= 6 * k
+    # the default rule: distributed from ADMM_HIP_DIST_TOP_MIN_NODES nodes on (300k; this bar has 2.4k), rank-local factorization either way
+    monkeypatch.delenv("ADMM_HIP_DIST_TOP")
+    s = pkg.make_bar_system(*dims, device_id=-1, rank=0, world=world, shard_mode="subtree"); s.initialize()
+    assert s.info()["dist_top"] == 0 and s.info()["factor_local"] == 1
+    monkeypatch.setenv("ADMM_HIP_DIST_TOP_MIN_NODES", "2000")
+    s = pkg.make_bar_system(*dims, device_id=-1, rank=0, world=world, shard_mode="subtree"); s.initialize()
+    assert s.info()["dist_top"] == 1
+    monkeypatch.delenv("ADMM_HIP_DIST_TOP_MIN_NODES")
     # without the knob a host-only context (no device, no transport) plans the replicated top of rounds 2-5
     monkeypatch.delenv("ADMM_HIP_PLAN_AS_IF_DEVICE")
     s = pkg.make_bar_system(*dims, device_id=-1, rank=0, world=world, shard_mode="subtree"); s.initialize()
@@ -390,6 +399,7 @@ def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
     assert sum(i["sweep_entries_top"] for i in d) == k * k                      # the ranks' row slices tile the root's inverse exactly
     # recompute_weights is collective too (every rank re-factors its share, the subtree roots' update matrices meet again): the anchors' weights
     # down to 0.5, every third tet's doubled -- the sharded solve of the NEW system equals the single-rank solve of the new system
+    monkeypatch.setenv("ADMM_HIP_DIST_TOP", "1")
     shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world, shard_mode="subtree") for r in range(world)]
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
@@ -445,8 +455,8 @@ def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(8, "subtree"), (4, "contiguous")])
-def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
+@pytest.mark.parametrize("world,mode", [(8, "subtree"), (8, "subtree-distributed-top"), (4, "contiguous")])
+def test_full_size_shards_vs_compiled_reference(pkg, monkeypatch, world, mode):
     """The headline workload as the multi-GPU runs cut it -- the 1,001,472-tet Neo-Hookean bar in 8 subtree shards (4 contiguous shards) -- on ONE
     GPU (one context and host thread per rank, the hook sums the ranks' buffers): after one frame of 20 iterations every rank holds the same bits,
     and they agree with the COMPILED REFERENCE's frame (tests/golden/traj_bar_1M.npz) within the bound every trajectory fixture uses, 20 x the
@@ -457,6 +467,8 @@ def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
         pytest.skip("full-size fixture not generated")
     g = golden("traj_bar_1M.npz")
     dims = [int(v) for v in g["dims"]]
+    if mode == "subtree-distributed-top":       # (178 596 nodes: replicated by default; the distributed top forced)
+        monkeypatch.setenv("ADMM_HIP_DIST_TOP", "1"); mode = "subtree"
     shards = [pkg.make_bar_system(*dims, rank=r, world=world, shard_mode=mode) for r in range(world)]
     hooks = _thread_allreduce_hooks(world)
     for r, s in enumerate(shards):
@@ -466,6 +478,8 @@ def test_full_size_shards_vs_compiled_reference(pkg, world, mode):
     assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"] and infos[0]["n_nodes"] == int(g["n_nodes"])
     if mode == "subtree":
         assert sum(i["nodes_own"] for i in infos) + infos[0]["nodes_top"] == infos[0]["n_nodes"]
+        assert all(i["factor_local"] == 1 and i["factor_doubles_resident"] < 0.6 * infos[0]["panel_bytes"] / 8 for i in infos)      # nobody holds the whole factor
+        assert infos[0]["dist_top"] == (1 if os.environ.get("ADMM_HIP_DIST_TOP") == "1" else 0)
         assert 8 * infos[0]["comm_doubles_iter"] < 1 << 20                   # well under a megabyte per iteration (the whole RHS is 4.29 MB)
     out = [None] * world
     errs = []
@@ -616,9 +630,9 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     for k, v in two["per_rank_summary"].items():
         assert v["slowest"] >= v["fastest"] >= 0 and v["slowest"] == max(pr[k])
     cm, sh, inf1 = two["comm"], two["shard"], one["config"]
-    assert cm["collectives_per_iter"] == 2 and cm["collectives_per_frame_extra"] == 1 and cm["allreduce_ms_per_iter"] > 0           # distributed top: [top rows in | the top's x out]
+    assert cm["collectives_per_iter"] == 1 and cm["collectives_per_frame_extra"] == 1 and cm["allreduce_ms_per_iter"] > 0           # (3 321 nodes: the replicated top, one collective; N = 4 / 8 below: distributed)
     assert cm["bytes_per_frame_extra"] == 8 * 3 * 9 * 9 * 41 and 0 < cm["bytes_per_iter"] < cm["bytes_per_frame_extra"]      # the top rows only, not the whole RHS
-    assert len(cm["bytes_per_collective"]) == 2 and sum(cm["bytes_per_collective"]) == cm["bytes_per_iter"] and cm["bytes_per_collective"][1] == 8 * 3 * sh["nodes_top"] and cm["top"].startswith("distributed")
+    assert cm["bytes_per_collective"] == cm["bytes_per_iter"] and cm["top"].startswith("replicated") and two["factor"]["rank_local"] is True
     assert sh["mode"] == "subtree" and sh["nodes_top"] > 0 and sh["nodes_own"] == pr["nodes_own"][0] and sum(pr["nodes_own"]) + sh["nodes_top"] == 9 * 9 * 41
     assert sh["sweep_entries_top_bwd"] <= sh["sweep_entries_top"] and 0 < sh["replicated_top_share_of_fwd_bytes"] < 1
     assert two["rccl_async_error"] == 0 and "graph_state" in two
@@ -659,7 +673,7 @@ def test_bench_n_ranks_end_to_end(n):
     list N long, the ranks' elements a partition, every rank factored only its share, the final positions those of the one-rank run."""
     import json
     one = _bench_one_rank_line()
-    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ADMM_HIP_DIST_TOP="1")      # (the distributed top: by default only from 300k nodes on)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + _BENCH_NRANK_ARGS, capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -678,7 +692,7 @@ def test_bench_n_ranks_end_to_end(n):
     fl = L["factor"]
     assert fl["rank_local"] is True and fl["exchange_bytes_once"] > 0
     assert max(pr["factor_mb_resident"]) < fl["whole_mb"] and sum(pr["factor_mb_resident"]) < fl["whole_mb"] * (1.0 + n * sh["replicated_top_share_of_all_entries"] + 0.3)
-    assert L["rccl_async_error"] == 0
+    assert L["rccl_async_error"] == 0 and L["comm"]["collectives_per_iter"] == 2 and L["comm"]["top"].startswith("distributed")
     assert abs(L["config"]["x_checksum"] - one["config"]["x_checksum"]) < 1e-6 * one["config"]["x_checksum"]
 
 

@@ -15,7 +15,7 @@ print('tets+anchors per GPU: all; nodes %s; nnz(L) %.4g; levels %d; initialize %
 print('ms per ADMM iteration: total %.4f = local %.4f + rhs %.4f + forward %.4f + backward %.4f;  value %.4g iters/s x tets' % (p['total_ms'], p['local_ms'], p['rhs_ms'], p['solve_fwd_ms'], p['solve_bwd_ms'], L['value']))
 " >> $OUT 2>&1
 for w in 2 4 8; do
-  echo "== $w ranks (subtree shards, rank-local factorization)" >> $OUT
+  echo "== $w ranks (subtree shards, rank-local factorization; ADMM_HIP_DIST_TOP=${ADMM_HIP_DIST_TOP:-auto})" >> $OUT
   timeout 2400 python tools/ranks_one_gpu.py --world $w --dims $NX $NY $NZ --warm 2 --frames $FR 2>&1 | grep -v amdgpu.ids >> $OUT
 done
 cat $OUT
