@@ -170,9 +170,14 @@ def _bench_fake(tmp_path, shard, graph_comm, dims, port, extra_env=None):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shard", shard, "--no-cpu-baseline", "--no-extras", "--steps", "3", "--warmup", "1", "--dims"] + [str(d) for d in dims]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    from test_sharding import _free_port
+    for attempt in range(3):      # (a port that was free a moment ago can be taken by the time the launcher binds it -- other tests' ranks come and go: try another one)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shard", shard, "--no-cpu-baseline", "--no-extras", "--steps", "3", "--warmup", "1", "--dims"] + [str(d) for d in dims]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+        port = _free_port()
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
