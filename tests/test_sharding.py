@@ -379,8 +379,14 @@ def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
     b = np.random.default_rng(9).normal(size=3 * ref.n_nodes)
     xref = ref.solve_only(b)
     infos = {}
-    for knob in ("1", "0"):
-        monkeypatch.setenv("ADMM_HIP_DIST_TOP", knob)
+    # "1" / "0": the two tops; "host": the distributed top with the numeric factorization on the HOST (ADMM_HIP_FACTOR=host: the whole factor there, every rank
+    # uploads its own panels and its rows of the root's inverse); "whole": ADMM_HIP_FACTOR_LOCAL=0, the round-5 scheme (every rank factors and keeps everything)
+    for knob in ("1", "0", "host", "whole"):
+        monkeypatch.setenv("ADMM_HIP_DIST_TOP", "0" if knob in ("0", "whole") else "1")
+        if knob == "host": monkeypatch.setenv("ADMM_HIP_FACTOR", "host")
+        else: monkeypatch.delenv("ADMM_HIP_FACTOR", raising=False)
+        if knob == "whole": monkeypatch.setenv("ADMM_HIP_FACTOR_LOCAL", "0")
+        else: monkeypatch.delenv("ADMM_HIP_FACTOR_LOCAL", raising=False)
         shards = [pkg.make_bar_system(*dims, kind=pkg.KIND["TET_STVK"], rank=r, world=world, shard_mode="subtree") for r in range(world)]
         hooks = _thread_allreduce_hooks(world)
         for r, s in enumerate(shards):
@@ -393,7 +399,10 @@ def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
             assert np.array_equal(out[r][1][-1], out[0][1][-1]) and np.array_equal(out[r][2], out[0][2]), (knob, r)
         assert sum(i["n_elems_local"] for i in infos[knob]) == ref.info()["n_elems_total"]
     d, rp = infos["1"], infos["0"]
-    assert all(i["dist_top"] == 1 and i["factor_local"] == 1 for i in d) and all(i["dist_top"] == 0 for i in rp)
+    assert all(i["dist_top"] == 1 and i["factor_local"] == 1 for i in d) and all(i["dist_top"] == 0 and i["factor_local"] == 1 for i in rp)
+    assert all(i["dist_top"] == 1 and i["device_factor"] == 0 and i["factor_doubles_resident"] == j["factor_doubles_resident"] for i, j in zip(infos["host"], d))
+    assert all(i["factor_local"] == 0 and i["dist_top"] == 0 and 8 * i["factor_doubles_resident"] == i["panel_bytes"] and i["factor_exchange_doubles"] == 0 for i in infos["whole"])
+    assert all(8 * i["factor_doubles_resident"] < i["panel_bytes"] and i["factor_exchange_doubles"] > 0 and i["device_factor"] == 1 for i in d + rp)
     assert all(i["sweep_entries_top_bwd"] == 0 for i in d)
     k = d[0]["nodes_top"]
     assert sum(i["sweep_entries_top"] for i in d) == k * k                      # the ranks' row slices tile the root's inverse exactly
