@@ -436,10 +436,10 @@ def main():
             hang["calls"] += 1
             if hang["armed"] and hang["rank"] == rank and hang["calls"] > hang["after"]:      # test hook (tests/test_sharding.py): this rank never reaches the collective again
                 time.sleep(1e6)
-            t = holder.get(ptr)
+            t = holder.get((ptr, count))      # (keyed by address AND count: the factorization's exchange buffers are freed again, and the allocator hands their addresses to other buffers)
             if t is None:
                 t = torch.as_tensor(_Ptr(ptr, count), device=torch.device("cuda", local_rank))
-                holder[ptr] = t
+                holder[(ptr, count)] = t
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return 0
         # RCCL inside the library: ncclAllReduce on the solver's stream straight from the C step loop.  torch.distributed's
