@@ -118,12 +118,12 @@ int admm_hip_add_explicit(admm_hip_ctx *ctx, int type, const double *dir, int n_
 int admm_hip_set_collision_shapes(admm_hip_ctx *ctx, int n_shapes, const int32_t *types, const double *params);
 
 /* ---- multi-GPU ------------------------------------------------------------
- * Elements shard across ranks (contiguous element ranges per batch); nodes and
- * the factor are replicated.  Must be called before finalize.  The hook is
- * invoked once per ADMM iteration between RHS assembly and the solve with the
- * device pointer of the partial RHS (count doubles, on `stream`): it must
- * sum it in place across ranks (RCCL all-reduce).  No reference counterpart
- * (the reference is single-process).                   */
+ * Elements shard across ranks (see admm_hip_set_shard_mode); must be called before finalize.  The hook must sum `count`
+ * doubles of a DEVICE buffer in place across the ranks (an all-reduce), ordered on `stream`; every rank makes the same
+ * calls in the same order, buffers and counts differ between calls: per ADMM iteration once (contiguous shards: the
+ * whole right-hand side; subtree shards: the top rows) or twice (distributed top: also the top's x), once per frame
+ * (subtree shards: the full x), and inside admm_hip_finalize / admm_hip_recompute_weights under rank-local factorization
+ * (admm_hip_set_factor_local).  No reference counterpart (the reference is single-process).   */
 typedef int (*admm_hip_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *hip_stream);
 int admm_hip_set_shard(admm_hip_ctx *ctx, int rank, int world);
 int admm_hip_set_allreduce(admm_hip_ctx *ctx, admm_hip_allreduce_fn fn, void *user);
@@ -161,7 +161,10 @@ int admm_hip_allreduce_host(admm_hip_ctx *ctx, double *host_buf, int64_t count);
  *   ADMM_SHARD_SUBTREE     the elimination tree is cut below its top: every rank owns whole subtrees and the elements touching
  *                          them (an element's nodes lie in one subtree plus separators above it); per iteration ONE small
  *                          all-reduce carries the top separators' partial right-hand sides and the subtree roots' contributions,
- *                          only the top levels of the solve are replicated, and the full x is rebuilt once per frame.
+ *                          only the top levels of the solve are replicated, and the full x is rebuilt once per frame.  With
+ *                          2 / 4 / 8 / 16 ranks and >= 300k nodes (ADMM_HIP_DIST_TOP) the top is ONE root supernode whose product
+ *                          with its explicit inverse is split by rows across the ranks: nothing of the solve is replicated, a
+ *                          second small all-reduce per iteration gathers the top's x (admm_hip_info.dist_top).
  * admm_hip_local_elements: this rank's elements of a batch (ascending reference order) -- the order of read_local / write_local. */
 enum { ADMM_SHARD_CONTIGUOUS = 0, ADMM_SHARD_SUBTREE = 1 };
 int admm_hip_set_shard_mode(admm_hip_ctx *ctx, int mode);
@@ -293,7 +296,7 @@ typedef struct admm_hip_info {
     int64_t sweep_entries_top;      /* the replicated top of the tree (forward sweep: all of it, on every rank)              */
     int64_t sweep_entries_top_bwd;  /* the part of the top this rank's backward sweep covers (separators it reads + ancestors) */
     int64_t nodes_own, nodes_top;   /* nodes of the own subtrees / of the replicated top                                     */
-    int64_t comm_doubles_iter;      /* doubles summed across the ranks per ADMM iteration (one collective)                   */
+    int64_t comm_doubles_iter;      /* doubles summed across the ranks per ADMM iteration (one collective; two with dist_top) */
     int64_t comm_doubles_frame;     /* additionally once per frame (subtree shards: the full x before the velocity update)   */
     /* rank-local factorization (subtree shards, admm_hip_set_factor_local): what THIS rank factors and keeps on its device   */
     int64_t factor_doubles_resident; /* doubles of factor panels (+ root inverses) resident on this rank's device; one rank / contiguous shards /
