@@ -75,12 +75,14 @@ public:
 
     // Multi-GPU (no reference counterpart: the reference's element loop, System.cpp:57-58, is one OpenMP team).  One process
     // per GPU, every process builds the SAME System (all nodes, all forces, same order) and sets its rank before initialize():
-    // the elements shard across the ranks, the partial right-hand sides meet in one all-reduce per ADMM iteration inside the
-    // library, and m_x / m_v are complete on every rank after every step().  Pre-step callbacks, control points and
-    // recompute_weights() must run identically on all ranks.
+    // the elements shard across the ranks, the partial right-hand sides meet in one (distributed top: two) small all-reduce(s) per ADMM
+    // iteration inside the library, and m_x / m_v are complete on every rank after every step().  Pre-step callbacks, control points and
+    // recompute_weights() must run identically on all ranks; under subtree shards initialize() and recompute_weights() are COLLECTIVE calls
+    // (every rank factors only its own elimination subtrees + its part of the top; the subtree roots' update matrices meet in one all-reduce).
     struct Shard {
         int rank, world;
         int mode;                        // ADMM_SHARD_SUBTREE (default: ranks own elimination subtrees, small exchange) or ADMM_SHARD_CONTIGUOUS
+        bool factor_local;               // subtree shards: every rank factors and keeps its own share (default; false: the whole matrix on every rank, initialize() stays local)
         // RCCL (default transport): rank 0 publishes the communicator's 128-byte id in this file, the others wait for it
         // (Comm.hpp rccl_id_via_file; a path unique to the job, on a filesystem all ranks see)
         std::string rccl_id_file;
@@ -89,7 +91,7 @@ public:
         // (admm_hip_set_host_allreduce, e.g. comm::ShmAllReduce::hook) in place across the ranks
         admm_hip_allreduce_fn allreduce; void *allreduce_user;
         admm_hip_host_allreduce_fn host_allreduce; void *host_allreduce_user;
-        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), rendezvous_timeout_s(600.0), rendezvous_max_age_s(600.0),
+        Shard() : rank(0), world(1), mode(ADMM_SHARD_SUBTREE), factor_local(true), rendezvous_timeout_s(600.0), rendezvous_max_age_s(600.0),
                   allreduce(nullptr), allreduce_user(nullptr), host_allreduce(nullptr), host_allreduce_user(nullptr) {}
         // what a launcher exports: torchrun / torch.distributed.run (RANK, WORLD_SIZE, LOCAL_RANK), Open MPI, Slurm;
         // ADMM_HIP_RCCL_ID_FILE names the rendezvous file.  Returns the local rank (the caller's device_id), or -1 if no launcher is seen.
@@ -356,7 +358,7 @@ protected:
         ++init_count;
         if (shard.world <= 1) return true;
         if (shard.rank < 0 || shard.rank >= shard.world) { std::cerr << "\n**Solver Error: shard.rank " << shard.rank << " outside [0, " << shard.world << ")" << std::endl; return false; }
-        if (!check(admm_hip_set_shard(gpu, shard.rank, shard.world)) || !check(admm_hip_set_shard_mode(gpu, shard.mode))) return false;
+        if (!check(admm_hip_set_shard(gpu, shard.rank, shard.world)) || !check(admm_hip_set_shard_mode(gpu, shard.mode)) || !check(admm_hip_set_factor_local(gpu, shard.factor_local ? 1 : 0))) return false;
         if (shard.host_allreduce) return check(admm_hip_set_host_allreduce(gpu, shard.host_allreduce, shard.host_allreduce_user));
         if (shard.allreduce) return check(admm_hip_set_allreduce(gpu, shard.allreduce, shard.allreduce_user));
         unsigned char id[128];
