@@ -163,6 +163,11 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         int merge_small = ctx->merge_small;
         if (own_subtrees && merge_small == 0 && share >= 4096) merge_small = (int)std::min<int64_t>(share * 4 / 3, 2000000000);      // (tiny shares: a merged node that moves to the top would be a large part of the system)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
+        // ... while the merged nodes stay small (round 6): the rule above was measured on the 1M-tet bar (33 x 33 separators, merged nodes of <= 3.3k columns).  On a thick mesh the
+        // same rule merges whole cross-sections -- 4M-tet bar (65 x 65 separators), 2 ranks: factor 7.5 -> 9.6 GB, slowest rank's kernels 1.75 -> 1.91 ms -- so a region whose merged
+        // node would exceed small_sep_cap columns stays binary (profiles/r06/merge_small_sharded_*.txt)
+        int small_sep_cap = own_subtrees ? 4096 : 0;
+        if (const char *e = getenv("ADMM_HIP_MERGE_SMALL_CAP")) small_sep_cap = atoi(e);
         // eight-way nodes (seven separators in one supernode) save one more level between 6k and 30k nodes: configs[2] (10k nodes) -4 %, 26.9k -1.7 %
         // (tools/probe/env_ab.py ADMM_HIP_MERGE_DEPTH 2 3, four alternations); 47.5k nodes +2 %, 63k and above +15 %: four-way there
         int merge_depth = (!own_subtrees && ctx->n_nodes >= 6000 && ctx->n_nodes < 30000) ? 3 : 2;
@@ -180,7 +185,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
             int d = 0; while ((1 << d) < ctx->world) ++d;
             d = std::max(d, 2);      // (2 ranks: four subtrees, two per rank -- the merged-root tree of rounds 2-5; one level less inside a rank's subtrees than a two-way root)
             Factor T;
-            analyze(ctx->A, xyz.data(), leaf, T, merge_above, false, merge_small, merge_depth, d, true);
+            analyze(ctx->A, xyz.data(), leaf, T, merge_above, false, merge_small, merge_depth, d, true, small_sep_cap);
             const int ns = (int)T.sn.size();
             int roots = 0, kids = 0; bool ok = ns > 0;
             for (int sn = 0; sn < ns; ++sn) { if (T.sn[sn].parent < 0) ++roots; else if (T.sn[sn].parent == ns - 1) ++kids; }
@@ -190,7 +195,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
             else if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: distributed top: the dissection gives %d roots / %d subtrees (wanted %d for %d ranks) -- replicated top instead\n", roots, kids, 1 << d, ctx->world);
         }
         if (!ctx->dist_top)
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth, false, small_sep_cap);
         // Tree search (systems between the dense limit and 160k nodes on one GPU, no ordering knob set by hand): the thresholds above were
         // measured on bars; other shapes get the same trade-off from a cost model of the two sweeps fitted to 192 measured (scene, tree) pairs
         // (tools/probe/tree_model_data.py, NOTES section E): 11.9 us per level below the roots (both sweeps: launch + dependent chain), 0.48 us per MB
@@ -198,7 +203,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // within 5 % of the best of 24 trees on every held-out scene.  Candidates: leaves of 64 / 128 / 256, four- or eight-way nodes, the root
         // spanning 4 bisection levels or not; ordering + symbolic analysis cost 2-60 ms each.  The rule-based tree stays unless the model
         // sees at least 3 % in another one.
-        const bool by_hand = getenv("ADMM_HIP_LEAF") || getenv("ADMM_HIP_MERGE") || getenv("ADMM_HIP_MERGE_ROOT") || getenv("ADMM_HIP_MERGE_SMALL") || getenv("ADMM_HIP_MERGE_DEPTH") ||
+        const bool by_hand = getenv("ADMM_HIP_LEAF") || getenv("ADMM_HIP_MERGE") || getenv("ADMM_HIP_MERGE_ROOT") || getenv("ADMM_HIP_MERGE_SMALL") || getenv("ADMM_HIP_MERGE_SMALL_CAP") || getenv("ADMM_HIP_MERGE_DEPTH") ||
                              getenv("ADMM_HIP_ROOT_DEPTH") || ctx->leaf_size > 0 || ctx->merge_small > 0;
         if (ctx->tree_search && !by_hand && !own_subtrees && ctx->world == 1 && ctx->n_nodes > ctx->dense_max && ctx->n_nodes < 160000) {
             auto model_us = [&](const Factor &T) {
