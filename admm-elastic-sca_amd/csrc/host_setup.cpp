@@ -161,12 +161,13 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // Per-rank forward + backward (tools/fake_world_policy.sh, no-op all-reduce): 8 ranks 0.198 -> 0.173 ms (thresholds 20k / 30k / 40k /
         // 60k: 0.181 / 0.173 / 0.173 / 0.234), 4 ranks 0.247 -> 0.220 (30k: 0.225, 60k: 0.220), 2 ranks 0.299 -> 0.281 (60k / 120k alike).
         int merge_small = ctx->merge_small;
-        if (own_subtrees && merge_small == 0 && share >= 4096) merge_small = (int)std::min<int64_t>(share * 4 / 3, 2000000000);      // (tiny shares: a merged node that moves to the top would be a large part of the system)
+        // (round 6, profiles/r06/merge_small_sharded_*.txt: that holds while a rank's levels are latency-bound -- shares up to ~100k nodes.  Beyond, a level streams hundreds of MB and
+        //  the four-way nodes' extra fill costs more than the level they save: 4M-tet bar, 2 ranks: factor 7.9 -> 9.6 GB, slowest rank's kernels 1.75 -> 1.91 ms; 16M tets, 2 ranks:
+        //  10.6 ms with the rule against 9.9 with most of it capped.  There only the regions next to the leaves merge.)
+        if (own_subtrees && merge_small == 0 && share >= 4096) merge_small = share <= 100000 ? (int)(share * 4 / 3) : 4000;      // (tiny shares: a merged node that moves to the top would be a large part of the system)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
-        // ... while the merged nodes stay small (round 6): the rule above was measured on the 1M-tet bar (33 x 33 separators, merged nodes of <= 3.3k columns).  On a thick mesh the
-        // same rule merges whole cross-sections -- 4M-tet bar (65 x 65 separators), 2 ranks: factor 7.5 -> 9.6 GB, slowest rank's kernels 1.75 -> 1.91 ms -- so a region whose merged
-        // node would exceed small_sep_cap columns stays binary (profiles/r06/merge_small_sharded_*.txt)
-        int small_sep_cap = own_subtrees ? 4096 : 0;
+        // a cap on the merged node's columns (3 x the region's separator; ADMM_HIP_MERGE_SMALL_CAP):
+        int small_sep_cap = 0;      // (measured, not adopted: the region-size rule above separates the cases better than a cap on the merged node's columns)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL_CAP")) small_sep_cap = atoi(e);
         // eight-way nodes (seven separators in one supernode) save one more level between 6k and 30k nodes: configs[2] (10k nodes) -4 %, 26.9k -1.7 %
         // (tools/probe/env_ab.py ADMM_HIP_MERGE_DEPTH 2 3, four alternations); 47.5k nodes +2 %, 63k and above +15 %: four-way there
