@@ -161,11 +161,13 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // Per-rank forward + backward (tools/fake_world_policy.sh, no-op all-reduce): 8 ranks 0.198 -> 0.173 ms (thresholds 20k / 30k / 40k /
         // 60k: 0.181 / 0.173 / 0.173 / 0.234), 4 ranks 0.247 -> 0.220 (30k: 0.225, 60k: 0.220), 2 ranks 0.299 -> 0.281 (60k / 120k alike).
         int merge_small = ctx->merge_small;
-        // (round 6, profiles/r06/merge_small_sharded_*.txt: that holds while a rank's levels are latency-bound -- shares up to ~100k nodes.  Beyond, a level streams hundreds of MB and
-        //  the four-way nodes' extra fill costs more than the level they save: 4M-tet bar, 2 ranks: factor 7.9 -> 9.6 GB, slowest rank's kernels 1.75 -> 1.91 ms; 16M tets, 2 ranks:
-        //  10.6 ms with the rule against 9.9 with most of it capped.  There only the regions next to the leaves merge.)
-        if (own_subtrees && merge_small == 0 && share >= 4096) merge_small = share <= 100000 ? (int)(share * 4 / 3) : 4000;      // (tiny shares: a merged node that moves to the top would be a large part of the system)
-        if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) merge_small = atoi(e);
+        // (round 6, profiles/r06/merge_small_sharded_*.txt: that holds while a rank's levels are latency-bound.  Where a rank streams more than ~100 MB per level of its subtrees the
+        //  four-way nodes' extra fill costs more than the levels they save -- 4M-tet bar, 2 ranks: factor 7.9 -> 9.6 GB, slowest rank's kernels 1.74 -> 1.91 ms; 16M tets: 9.6 / 5.2 / 3.0
+        //  against 10.6 / 5.6 / 3.2 ms at 2 / 4 / 8 ranks -- so the tree is built with this rule first and, if its levels turn out byte-bound, again with four-way nodes next to the
+        //  leaves only (regions of <= 4000 nodes): see below.)
+        bool merge_small_by_rule = false;
+        if (own_subtrees && merge_small == 0 && share >= 4096) { merge_small = (int)std::min<int64_t>(share * 4 / 3, 2000000000); merge_small_by_rule = true; }      // (tiny shares: a merged node that moves to the top would be a large part of the system)
+        if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) { merge_small = atoi(e); merge_small_by_rule = false; }
         // a cap on the merged node's columns (3 x the region's separator; ADMM_HIP_MERGE_SMALL_CAP):
         int small_sep_cap = 0;      // (measured, not adopted: the region-size rule above separates the cases better than a cap on the merged node's columns)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL_CAP")) small_sep_cap = atoi(e);
@@ -180,6 +182,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // explicit inverse (what merge_root does on one GPU), and that product is split by rows across the ranks -- every rank streams 1 / world of
         // the inverse and the slices meet in a second small collective -- instead of every rank sweeping a replicated top of several levels: the
         // replicated top's bytes grow with the rank count (4M-tet bar: 0.85 GB at 4 ranks, 1.66 GB of a rank's 2.4 GB at 8), the split root's shrink.
+        auto build_tree = [&]() {
         ctx->dist_top = false;
         if (own_subtrees && (ctx->dist_top_wanted == 1 || (ctx->dist_top_wanted < 0 && ctx->n_nodes >= ctx->dist_top_min_nodes)) && ctx->factor_local && ctx->root_inverse && ((ctx->device_id >= 0 && (ctx->rccl_comm || ctx->allreduce)) || getenv("ADMM_HIP_PLAN_AS_IF_DEVICE")) &&
             (ctx->world & (ctx->world - 1)) == 0 && ctx->world <= 16 && ctx->n_nodes > ctx->dense_max && !getenv("ADMM_HIP_ROOT_DEPTH") && !getenv("ADMM_HIP_MERGE_ROOT")) {
@@ -197,6 +200,22 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         }
         if (!ctx->dist_top)
         analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth, false, small_sep_cap);
+        };
+        build_tree();
+        if (merge_small_by_rule) {
+            // what a rank streams per level of its own subtrees, on average (the root of a distributed top is streamed as its inverse, not as a panel)
+            const Factor &T = ctx->F;
+            double entries = (double)T.nnz_tri;
+            if (ctx->dist_top) { const Supernode &R = T.sn.back(); entries -= (double)R.ncols * (R.ncols + 1) / 2; }
+            const double mb_per_level = 8e-6 * entries / std::max(1, ctx->world) / std::max<size_t>(1, T.levels.size());
+            if (mb_per_level > 100.0) {
+                if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: a rank streams %.0f MB per level of its subtrees: byte-bound levels -- four-way nodes only next to the leaves (merge_small %d -> 4000)\n", mb_per_level, merge_small);
+                const double t_o = T.t_order, t_s = T.t_symbolic;
+                merge_small = 4000;
+                build_tree();
+                ctx->F.t_order += t_o; ctx->F.t_symbolic += t_s;
+            }
+        }
         // Tree search (systems between the dense limit and 160k nodes on one GPU, no ordering knob set by hand): the thresholds above were
         // measured on bars; other shapes get the same trade-off from a cost model of the two sweeps fitted to 192 measured (scene, tree) pairs
         // (tools/probe/tree_model_data.py, NOTES section E): 11.9 us per level below the roots (both sweeps: launch + dependent chain), 0.48 us per MB
