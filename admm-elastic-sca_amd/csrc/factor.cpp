@@ -121,7 +121,6 @@ struct ND {
     bool merge_root = false;
     int merge_small = 0;      // regions of at most that many nodes (and more than a leaf) become four-way nodes as well: one level less near the leaves
     int root_depth = 0;       // > 1: bisection levels the ROOT node spans (whatever the other nodes do)
-    int small_sep_cap = 0;    // > 0: merge_small regions whose separator has more than small_sep_cap / 3 nodes stay binary
     bool root_exact = false;  // root_depth >= 1 is binding: the root has exactly 2^root_depth children (subtree sharding's distributed top: one subtree per rank)
     int merge_depth = 2;      // bisection levels a merged node spans: 2 = four-way (three separators in one supernode), 3 = eight-way (seven)
     // the part `H` of a merged node: its separators down to `d` more bisections join `cols`, what is left below becomes children
@@ -139,14 +138,10 @@ struct ND {
         if (m <= leaf) return emit(nodes);
         bool four = (merge > 0 && m > merge) || (merge_root && depth == 0) || (merge_small > 0 && m <= merge_small) || (root_depth > 1 && depth == 0);
         if (root_exact && depth == 0) four = root_depth > 1;      // the root spans EXACTLY root_depth bisection levels (1: a plain binary root), whatever the merge rules say
-        const bool by_small_only = four && (merge_small > 0 && m <= merge_small) && !(merge > 0 && m > merge) && !(merge_root && depth == 0) && !(root_depth > 1 && depth == 0);
         std::vector<int> L, R, sep;
         bisect(nodes, L, R, sep);
         // the merged root's explicit inverse is k x k with k ~ 3 separators: only while that stays a modest stream (<= 134 MB)
         if (four && merge_root && depth == 0 && !(merge > 0 && m > merge) && 3 * sep.size() > 4096) four = false;
-        // four-way nodes "near the leaves" (merge_small) buy a level for fill ~ (3 separators)^2: worth it while the separators are small -- a region
-        // whose separator is a whole cross-section of a thick mesh stays binary (small_sep_cap: columns the merged node may have at the most)
-        if (by_small_only && small_sep_cap > 0 && 3 * (int)sep.size() > small_sep_cap) four = false;
         std::vector<int> kids;
         std::vector<int> cols;
         if (four) {
@@ -167,7 +162,7 @@ struct ND {
 };
 } // namespace
 
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth, bool root_exact, int small_sep_cap) {
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above, bool merge_root, int merge_small, int merge_depth, int root_depth, bool root_exact) {
     const double t0 = now_s();
     const int n = A.n;
     F = Factor();
@@ -181,7 +176,7 @@ int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int me
         std::vector<int64_t> pos(adjp.begin(), adjp.end() - 1);
         for (int j = 0; j < n; ++j) for (int64_t p = A.ptr[j]; p < A.ptr[j + 1]; ++p) { int i = A.idx[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
     }
-    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth; nd.root_exact = root_exact && root_depth >= 1; nd.small_sep_cap = small_sep_cap;
+    ND nd; nd.adjp = &adjp; nd.adj = &adj; nd.xyz = xyz; nd.leaf = std::max(1, leaf_size); nd.merge = merge_above; nd.merge_root = merge_root; nd.merge_small = merge_small; nd.merge_depth = std::max(2, merge_depth); nd.root_depth = root_depth; nd.root_exact = root_exact && root_depth >= 1;
     nd.tag.assign(n, 0); nd.order.reserve(n);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);

@@ -68,9 +68,8 @@ void build_symcsc(int n, const std::vector<int> &ti, const std::vector<int> &tj,
 // merge_root: the top region alone does (one root supernode = top separator + the two half-separators)
 // merge_small > 0: regions of at most that many nodes (above the leaf size) become four-way nodes too (fewer, fatter levels near the leaves)
 // merge_depth: bisection levels a merged node spans (2: four-way nodes, 3: eight-way nodes with seven separators in one supernode);
-// root_depth > 1: the same for the root node alone; root_exact: the root spans exactly root_depth >= 1 bisection levels (2^root_depth children);
-// small_sep_cap > 0: a merge_small region becomes a four-way node only if the merged node keeps at most that many columns (3 x its separator)
-int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0, bool root_exact = false, int small_sep_cap = 0);
+// root_depth > 1: the same for the root node alone; root_exact: the root spans exactly root_depth >= 1 bisection levels (2^root_depth children)
+int analyze(const SymCSC &A, const double *xyz, int leaf_size, Factor &F, int merge_above = 0, bool merge_root = false, int merge_small = 0, int merge_depth = 2, int root_depth = 0, bool root_exact = false);
 
 // Layout of Factor::panels from the symbolic structure alone: Supernode::root_inv_off and Factor::panels_size.
 void plan_panels(Factor &F);

@@ -168,9 +168,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         bool merge_small_by_rule = false;
         if (own_subtrees && merge_small == 0 && share >= 4096) { merge_small = (int)std::min<int64_t>(share * 4 / 3, 2000000000); merge_small_by_rule = true; }      // (tiny shares: a merged node that moves to the top would be a large part of the system)
         if (const char *e = getenv("ADMM_HIP_MERGE_SMALL")) { merge_small = atoi(e); merge_small_by_rule = false; }
-        // a cap on the merged node's columns (3 x the region's separator; ADMM_HIP_MERGE_SMALL_CAP):
-        int small_sep_cap = 0;      // (measured, not adopted: the region-size rule above separates the cases better than a cap on the merged node's columns)
-        if (const char *e = getenv("ADMM_HIP_MERGE_SMALL_CAP")) small_sep_cap = atoi(e);
+        // (a cap on the merged node's columns instead -- 3 x the region's separator -- was measured and does not separate the cases: profiles/r06/merge_small_sharded_cap.txt)
         // eight-way nodes (seven separators in one supernode) save one more level between 6k and 30k nodes: configs[2] (10k nodes) -4 %, 26.9k -1.7 %
         // (tools/probe/env_ab.py ADMM_HIP_MERGE_DEPTH 2 3, four alternations); 47.5k nodes +2 %, 63k and above +15 %: four-way there
         int merge_depth = (!own_subtrees && ctx->n_nodes >= 6000 && ctx->n_nodes < 30000) ? 3 : 2;
@@ -189,7 +187,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
             int d = 0; while ((1 << d) < ctx->world) ++d;
             d = std::max(d, 2);      // (2 ranks: four subtrees, two per rank -- the merged-root tree of rounds 2-5; one level less inside a rank's subtrees than a two-way root)
             Factor T;
-            analyze(ctx->A, xyz.data(), leaf, T, merge_above, false, merge_small, merge_depth, d, true, small_sep_cap);
+            analyze(ctx->A, xyz.data(), leaf, T, merge_above, false, merge_small, merge_depth, d, true);
             const int ns = (int)T.sn.size();
             int roots = 0, kids = 0; bool ok = ns > 0;
             for (int sn = 0; sn < ns; ++sn) { if (T.sn[sn].parent < 0) ++roots; else if (T.sn[sn].parent == ns - 1) ++kids; }
@@ -199,7 +197,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
             else if (getenv("ADMM_HIP_VERBOSE")) fprintf(stderr, "admm_hip: distributed top: the dissection gives %d roots / %d subtrees (wanted %d for %d ranks) -- replicated top instead\n", roots, kids, 1 << d, ctx->world);
         }
         if (!ctx->dist_top)
-        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth, false, small_sep_cap);
+        analyze(ctx->A, xyz.data(), leaf, ctx->F, merge_above, merge_root, merge_small, merge_depth, root_depth);
         };
         build_tree();
         if (merge_small_by_rule) {
@@ -223,7 +221,7 @@ int host_factor(admm_hip_ctx *ctx, bool reuse_symbolic) {
         // within 5 % of the best of 24 trees on every held-out scene.  Candidates: leaves of 64 / 128 / 256, four- or eight-way nodes, the root
         // spanning 4 bisection levels or not; ordering + symbolic analysis cost 2-60 ms each.  The rule-based tree stays unless the model
         // sees at least 3 % in another one.
-        const bool by_hand = getenv("ADMM_HIP_LEAF") || getenv("ADMM_HIP_MERGE") || getenv("ADMM_HIP_MERGE_ROOT") || getenv("ADMM_HIP_MERGE_SMALL") || getenv("ADMM_HIP_MERGE_SMALL_CAP") || getenv("ADMM_HIP_MERGE_DEPTH") ||
+        const bool by_hand = getenv("ADMM_HIP_LEAF") || getenv("ADMM_HIP_MERGE") || getenv("ADMM_HIP_MERGE_ROOT") || getenv("ADMM_HIP_MERGE_SMALL") || getenv("ADMM_HIP_MERGE_DEPTH") ||
                              getenv("ADMM_HIP_ROOT_DEPTH") || ctx->leaf_size > 0 || ctx->merge_small > 0;
         if (ctx->tree_search && !by_hand && !own_subtrees && ctx->world == 1 && ctx->n_nodes > ctx->dense_max && ctx->n_nodes < 160000) {
             auto model_us = [&](const Factor &T) {
