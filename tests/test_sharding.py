@@ -438,6 +438,67 @@ def test_distributed_top_vs_replicated_top(pkg, monkeypatch, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,dist", [(4, "1"), (3, "0"), (2, "0")])
+def test_sharded_residuals_and_early_exit(pkg, monkeypatch, world, dist):
+    """Residual tracking under subtree sharding (SURVEY 8(f) rank 4 x 8(e)): |r|^2 is additive over the ranks' elements, s = D^T W^T W (z - z_prev) is a sum over
+    all ranks' elements -- both go through the all-reduce -- so every rank reports the single-rank norms (cloth: no truncated minimiser, 1e-9 relative), and a
+    tolerance ends the ADMM loop at the same iteration on every rank (distributed top at 4 ranks, replicated at 3 and 2)."""
+    monkeypatch.setenv("ADMM_HIP_DENSE_MAX", "0")
+    monkeypatch.setenv("ADMM_HIP_LEAF", "16")
+    monkeypatch.setenv("ADMM_HIP_DIST_TOP", dist)
+    from conftest import golden
+    g = golden("traj_cloth.npz")
+    n = g["x"].shape[0]
+
+    def cloth(rank, w):
+        s = pkg.System(device_id=0); s.set_timestep(float(g["dt"]))
+        s.add_nodes(g["x"].ravel(), np.full(3 * n, float(g["mass"])))
+        s.add_forces(pkg.KIND["TRI_STRAIN"], g["tris"], [float(g["k_tri"]), g["lim"][0], g["lim"][1], 1.0])
+        s.add_forces(pkg.KIND["BEND"], g["hinges"], [float(g["k_bend"])])
+        s.add_forces(pkg.KIND["ANCHOR"], g["anchors"], [-1.0, 1.0])
+        s.add_gravity([0, -9.8, 0])
+        if w > 1:
+            s.set_shard(rank, w); s.set_shard_mode("subtree")
+        return s
+    iters = 16
+    ref = cloth(0, 1); ref.initialize(); ref.enable_residuals(True)
+    ref.step(iters)
+    r1, s1, n1 = ref.residuals()
+    assert n1 == iters and r1[-1] < r1[0]
+    tol_r, tol_s = 1.2 * r1[9], 1.2 * s1[9]
+    ref2 = cloth(0, 1); ref2.initialize(); ref2.set_tolerance(tol_r, tol_s, 1); ref2.step(iters)
+    stop1 = ref2.residuals()[2]
+    assert 1 < stop1 < iters
+    for tolerances in (None, (tol_r, tol_s)):
+        shards = [cloth(r, world) for r in range(world)]
+        hooks = _thread_allreduce_hooks(world)
+        for r, sh in enumerate(shards):
+            sh.set_allreduce(hooks[r])
+        pkg.initialize_together(shards)
+        assert shards[0].info()["dist_top"] == int(dist)
+        out = [None] * world; errs = []
+
+        def run(r):
+            try:
+                if tolerances: shards[r].set_tolerance(tolerances[0], tolerances[1], 1)
+                else: shards[r].enable_residuals(True)
+                shards[r].step(iters)
+                out[r] = shards[r].residuals() + (shards[r].m_x.copy(),)
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, repr(e)))
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join(timeout=300) for t in th]
+        assert not errs and all(o is not None for o in out), errs
+        for r in range(world):
+            rr, ss, nn, xx = out[r]
+            if tolerances:
+                assert nn == stop1, (r, nn, stop1)                                   # the same iteration ends the loop on every rank, and it is the single-rank one
+            else:
+                assert nn == iters and np.allclose(rr, r1, rtol=1e-9, atol=1e-14) and np.allclose(ss, s1, rtol=1e-9, atol=1e-14), r
+            assert np.array_equal(xx, out[0][3])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_four_way_subtrees_match_single_rank(pkg, world):
     """Shares of >= 4096 nodes: regions up to 4/3 of a rank's share become four-way tree nodes inside the ranks' subtrees (host_factor); the
