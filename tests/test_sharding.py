@@ -573,6 +573,49 @@ def test_full_size_shards_vs_compiled_reference(pkg, monkeypatch, world, mode):
 
 
 @pytest.mark.gpu
+def test_4M_tet_bar_in_8_shards_matches_one_gpu(pkg):
+    """The configuration of the per-rank tables at the size where sharding pays (64x64x163 bar, 4 005 888 tets, 692 900 nodes, 8 ranks): above
+    300k nodes the top is DISTRIBUTED by default and a rank's subtrees are rebuilt with near-leaf four-way nodes only (its levels stream > 100 MB).  Against the
+    same bar on one GPU: the solve of a random right-hand side to 1e-10, one ADMM iteration from a deformed start to 1e-10 (local steps bit-identical, two
+    different eliminations), all ranks bitwise equal, nobody holds more than a quarter of what the one-GPU run holds."""
+    from checkers import deformed_start
+    dims, world = (64, 64, 163), 8
+    ref = pkg.make_bar_system(*dims); ref.initialize()
+    b = np.random.default_rng(4).normal(size=3 * ref.n_nodes)
+    xref = ref.solve_only(b)
+    x0 = deformed_start(ref.m_x)
+    ref.m_x = x0; ref.step(1)
+    x1 = ref.m_x.copy()
+    whole = ref.info()["panel_bytes"]
+    del ref
+    shards = [pkg.make_bar_system(*dims, rank=r, world=world, shard_mode="subtree") for r in range(world)]
+    hooks = _thread_allreduce_hooks(world)
+    for r, s in enumerate(shards):
+        s.set_allreduce(hooks[r]); s.keep_z(False)
+    pkg.initialize_together(shards)
+    infos = [s.info() for s in shards]
+    assert all(i["dist_top"] == 1 and i["factor_local"] == 1 for i in infos)
+    assert max(8 * i["factor_doubles_resident"] for i in infos) < 0.3 * whole
+    assert sum(i["n_elems_local"] for i in infos) == infos[0]["n_elems_total"]
+    out = [None] * world; errs = []
+
+    def run(r):
+        try:
+            sol = shards[r].solve_only(b)
+            shards[r].m_x = x0; shards[r].step(1)
+            out[r] = (sol, shards[r].m_x.copy())
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(timeout=900) for t in th]
+    assert not errs and all(o is not None for o in out), errs
+    for r in range(world):
+        assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][1], out[0][1]), r
+    assert np.abs(out[0][0] - xref).max() < 1e-10 * np.abs(xref).max()
+    assert np.abs(out[0][1] - x1).max() < 1e-10, np.abs(out[0][1] - x1).max()
+
+
+@pytest.mark.gpu
 def test_full_size_mixed_scene_in_8_shards_vs_compiled_reference(pkg):
     """BASELINE.json configs[4] as it is meant to run -- 498,888 NH + StVK tets, 99,856 cloth triangles, 149k hinges, anchors on "8 GPUs" -- as 8 subtree
     shards on ONE GPU: every force kernel of the scene under sharding (one launch per rank for its whole local step), two bodies = two elimination
