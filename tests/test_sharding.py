@@ -728,8 +728,11 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0 and "cpu_baseline" not in two
     assert two["rccl_ranks_seen"] == 2 and two["ranks_ok"] is True and "gloo" in two["config"]["allreduce"]
     # ... and as the driver launches it (torch.distributed.run around bench.py): same line
-    r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                         os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+    for attempt in range(3):      # (a port that was free a moment ago can be taken by the time the launcher binds it: try another one)
+        r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                             os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+        if r3.returncode == 0 or "EADDRINUSE" not in r3.stderr:
+            break
     assert r3.returncode == 0, r3.stderr[-3000:]
     three = json.loads([l for l in r3.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert three["n_gpus"] == 2 and three["config"]["x_checksum"] == two["config"]["x_checksum"]
